@@ -1,0 +1,142 @@
+"""Deterministic synthetic inputs for tests and bench.py.
+
+Mirrors the parameters of the reference's simulator
+(/root/reference/simulation/simulate_dag.R:106-115: SNP -> trait effects,
+trait -> trait DAG, unit noise) on genotypes with realistic block LD so that
+level-0 degrees look like an LD-pruned block: windows of `window` SNPs, latent
+AR(1) Gaussian (rho) inside a window, two latent copies thresholded at the
+MAF and summed to {0,1,2}.  Seeds: numpy Generator(PCG64(20251003 + block_index)).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+BASE_SEED = 20251003
+
+
+def rng_for(block_index: int = 0) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64(BASE_SEED + int(block_index)))
+
+
+def make_genotypes(m: int, N: int, rng, window: int = 100, rho: float = 0.85, miss: float = 0.001) -> np.ndarray:
+    """m x N int8 dosages in {0,1,2}, -1 = missing."""
+    from scipy.stats import norm
+
+    G = np.empty((m, N), np.int8)
+    maf = rng.uniform(0.05, 0.5, size=m)
+    thr = norm.ppf(1.0 - maf).astype(np.float32)
+    s = np.float32(np.sqrt(1.0 - rho * rho))
+    for w0 in range(0, m, window):
+        w1 = min(m, w0 + window)
+        acc = np.zeros((w1 - w0, N), np.int8)
+        for _copy in range(2):
+            z = rng.standard_normal((w1 - w0, N), dtype=np.float32)
+            for j in range(1, w1 - w0):
+                z[j] = np.float32(rho) * z[j - 1] + s * z[j]
+            acc += (z > thr[w0:w1, None]).astype(np.int8)
+        G[w0:w1] = acc
+    if miss > 0:
+        mask = rng.random((m, N), dtype=np.float32) < miss
+        G[mask] = -1
+    return G
+
+
+def make_traits(G: np.ndarray, p: int, rng, causal_per_1000: float = 5.0) -> np.ndarray:
+    """p x N float32 standardised traits: sparse SNP effects + lower-triangular trait DAG."""
+    m, N = G.shape
+    Y = np.zeros((p, N), np.float64)
+    ncausal = max(1, int(round(causal_per_1000 * m / 1000.0)))
+    for k in range(p):
+        idx = rng.choice(m, size=min(ncausal, m), replace=False)
+        beta = rng.uniform(0.02, 0.08, size=idx.size) * rng.choice([-1.0, 1.0], size=idx.size)
+        g = G[idx].astype(np.float64)
+        g[g < 0] = np.nan
+        mu = np.nanmean(g, axis=1, keepdims=True)
+        sd = np.nanstd(g, axis=1, keepdims=True)
+        sd[sd == 0] = 1.0
+        gs = np.nan_to_num((g - mu) / sd)
+        y = beta @ gs
+        for k2 in range(k):
+            if rng.random() < 3.0 / p:
+                y = y + rng.uniform(0.05, 0.2) * rng.choice([-1.0, 1.0]) * Y[k2]
+        y = y + rng.standard_normal(N)
+        Y[k] = (y - y.mean()) / y.std()
+    return Y.astype(np.float32)
+
+
+_CODE = np.array([3, 2, 0, 1], np.uint8)  # dosage 0,1,2,missing(-1) -> 2-bit code 11,10,00,01
+
+
+def pack_bed(G: np.ndarray) -> np.ndarray:
+    """m x ceil(N/4) uint8, PLINK SNP-major 2-bit codes, low bits first (no magic bytes).
+    Padding samples get code 0 like PLINK's writers."""
+    m, N = G.shape
+    codes = _CODE[G.astype(np.int64)]  # -1 indexes the last entry (missing)
+    pad = (-N) % 4
+    if pad:
+        codes = np.concatenate([codes, np.zeros((m, pad), np.uint8)], axis=1)
+    c = codes.reshape(m, -1, 4)
+    return (c[:, :, 0] | (c[:, :, 1] << 2) | (c[:, :, 2] << 4) | (c[:, :, 3] << 6)).astype(np.uint8)
+
+
+def bed_stats(G: np.ndarray):
+    """per-marker mean and population std over non-missing samples (reference prep.cpp:56-73)."""
+    g = G.astype(np.float64)
+    g[G < 0] = np.nan
+    return np.nanmean(g, axis=1).astype(np.float32), np.nanstd(g, axis=1).astype(np.float32)
+
+
+def synth_bed_block(m: int, N: int, p: int, block_index: int = 0, **kw):
+    """(bed bytes m x ceil(N/4), phen column-major p*N float32, means, stds, G)."""
+    rng = rng_for(block_index)
+    G = make_genotypes(m, N, rng, **kw)
+    Y = make_traits(G, p, rng)
+    means, stds = bed_stats(G)
+    return pack_bed(G), np.ascontiguousarray(Y).reshape(-1), means, stds, G
+
+
+def corr_from_samples(G: np.ndarray, Y: np.ndarray, device: str | None = None) -> np.ndarray:
+    """(m+p) x (m+p) float32 Pearson correlation of mean-imputed dosages and traits."""
+    m, N = G.shape
+    X = np.concatenate([G.astype(np.float32), Y.astype(np.float32)], axis=0)
+    X[:m][G < 0] = np.nan
+    mu = np.nanmean(X, axis=1, keepdims=True)
+    X = np.nan_to_num(X - mu)
+    X /= np.maximum(np.sqrt((X * X).sum(axis=1, keepdims=True)), 1e-30)
+    if device is not None:
+        import torch
+
+        t = torch.from_numpy(X).to(device)
+        Cm = (t @ t.T).float().cpu().numpy()
+    else:
+        Cm = X @ X.T
+    Cm = np.clip(Cm, -1.0, 1.0).astype(np.float32)
+    Cm = np.maximum(Cm, Cm.T) * (np.abs(Cm) >= np.abs(Cm.T)) + np.minimum(Cm, Cm.T) * (np.abs(Cm) < np.abs(Cm.T))
+    np.fill_diagonal(Cm, 1.0)
+    return np.ascontiguousarray(Cm, np.float32)
+
+
+def synth_corr_block(m: int, p: int, N: int = 16384, block_index: int = 0, device: str | None = None, **kw):
+    """Summary-statistics style input for cuskss: symmetric n x n fp32 correlation matrix."""
+    rng = rng_for(block_index)
+    G = make_genotypes(m, N, rng, **kw)
+    Y = make_traits(G, p, rng)
+    return corr_from_samples(G, Y, device)
+
+
+def random_corr(n: int, seed: int, k: int | None = None, strength: float = 1.0) -> np.ndarray:
+    """Small dense test matrix: sample correlation of a random sparse linear SEM
+    (recipe of /root/reference/cusk/scripts/skeleton_gen.py:19-90, own code)."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    k = k or 4 * n
+    B = np.tril(rng.random((n, n)) < min(1.0, 2.5 / n), -1) * rng.uniform(0.3, 0.9, (n, n)) * strength
+    B *= rng.choice([-1.0, 1.0], size=(n, n))
+    X = np.zeros((n, k))
+    E = rng.standard_normal((n, k))
+    for i in range(n):
+        X[i] = B[i] @ X + E[i]
+    Cm = np.corrcoef(X).astype(np.float32)
+    Cm = np.triu(Cm, 1)
+    Cm = Cm + Cm.T
+    np.fill_diagonal(Cm, 1.0)
+    return np.ascontiguousarray(Cm, np.float32)

@@ -1,0 +1,41 @@
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def kat():
+    with open(os.path.join(GOLDEN, "ref_kat.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_dir():
+    return os.path.join(GOLDEN, "files")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    from oracle import oracle as O
+
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def synth():
+    import cigwas_amd.synth as S
+
+    return S
