@@ -1,0 +1,76 @@
+"""ctypes loader of libcusk_hip.so (the product).  No fallback: if the HIP
+library is missing or cannot be loaded this raises, it never routes anywhere else."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "csrc", "libcusk_hip.so")
+ML = 14
+
+
+class CuskStats(C.Structure):
+    _fields_ = [
+        ("level", C.c_int),
+        ("levels_run", C.c_int),
+        ("max_degree", C.c_int * (ML + 1)),
+        ("edges", C.c_longlong * (ML + 1)),
+        ("tests", C.c_longlong * (ML + 1)),
+        ("subsets", C.c_longlong * (ML + 1)),
+        ("removed", C.c_longlong * (ML + 1)),
+        ("kernel_ms", C.c_float * (ML + 1)),
+        ("level_ms", C.c_float * (ML + 1)),
+        ("total_ms", C.c_float),
+    ]
+
+
+# every symbol include/cusk_hip.h declares: (restype, argtypes)
+_vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
+SYMBOLS = {
+    "Skeleton": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hetcor_skeleton": (None, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cusk_threshold_array": (None, [_i, _f, _vp]),
+    "cusk_hetcor_threshold": (_f, [_f]),
+    "cu_marker_phen_corr_pearson": (None, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "cu_corr_pearson_npn": (None, [_vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp, _vp]),
+    "cusk_engine_create": (_i, [C.POINTER(_vp), _i, _vp]),
+    "cusk_engine_destroy": (None, [_vp]),
+    "cusk_last_error": (C.c_char_p, [_vp]),
+    "cusk_engine_stream": (_vp, [_vp]),
+    "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
+    "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
+    "cusk_result_n": (_i, [_vp]),
+    "cusk_result_adj_bits_dev": (_vp, [_vp]),
+    "cusk_result_words": (_i, [_vp]),
+    "cusk_result_adj_i32": (_i, [_vp, _vp]),
+    "cusk_result_adj_i32_dev": (_i, [_vp, _vp]),
+    "cusk_result_pmax": (_i, [_vp, _vp, _vp]),
+    "cusk_result_sepset_dense": (_i, [_vp, _vp]),
+    "cusk_result_sepsets": (_ll, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cusk_corr_build": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "cusk_corr_timing": (None, [_vp, _vp]),
+    "cusk_dev_alloc": (_vp, [_sz]),
+    "cusk_dev_free": (None, [_vp]),
+    "cusk_dev_upload": (_i, [_vp, _vp, _sz]),
+    "cusk_dev_download": (_i, [_vp, _vp, _sz]),
+}
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError(
+                f"{SO_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C ci-gwas_amd/csrc).  There is no CPU fallback."
+            )
+        L = C.CDLL(SO_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)  # AttributeError if the library does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib

@@ -1,0 +1,446 @@
+// corr_build.hip -- SNP x SNP / SNP x trait / trait x trait correlations from packed .bed.
+//
+// Replaces /root/reference/cusk/src/corr_host.cu:1023-1197 (cu_marker_phen_corr_pearson,
+// cu_corr_pearson_npn) and the kernels they launch (src/corr_kernels.cu:157-238,
+// :285-343, :478-565; decode tables include/mps/bed_lut_gpu.h):
+//   mxm : Kendall tau-b from the 3x3 genotype contingency table over jointly
+//         non-missing individuals, mapped by sin(pi/2 tau)  (exact integer counts,
+//         the reference's fp32 epilogue order)
+//   mxp : Pearson with precomputed marker mean/std, NaN traits skipped
+//   pxp : sum(y_a y_b) / #jointly-valid
+// and writes the n x n square matrix of src/cli.cpp:597-649 straight into HBM
+// (markers first, traits last, unit diagonal, symmetric) so that the level
+// sweep can start without a host round trip.
+//
+// .bed 2-bit codes, low bits first: 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0.
+#include <cmath>
+#include <vector>
+
+#include "cusk_internal.h"
+
+namespace cusk {
+
+// ---------------------------------------------------------------------------
+// decode: .bed bytes -> three bit planes per marker (1 bit / individual)
+//   plane 0: genotype == 1, plane 1: genotype == 2, plane 2: non-missing
+// ---------------------------------------------------------------------------
+__global__ void bed_to_bitplanes_kernel(const unsigned char *__restrict__ bed, unsigned long long *planes, size_t m,
+                                        size_t N, size_t clb, size_t w64)
+{
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= m * w64) return;
+    const size_t mk = gid / w64, w = gid - mk * w64;
+    unsigned long long b1 = 0, b2 = 0, bv = 0;
+    const unsigned char *src = bed + mk * clb + w * 16;
+    for (int byte = 0; byte < 16; byte++)
+    {
+        const size_t bi = w * 16 + byte;
+        if (bi >= clb) break;
+        const unsigned v = src[byte];
+        for (int j = 0; j < 4; j++)
+        {
+            const size_t smp = bi * 4 + j;
+            if (smp >= N) break;
+            const unsigned code = (v >> (2 * j)) & 3u;
+            const unsigned long long bit = 1ull << (byte * 4 + j);
+            if (code == 2u) b1 |= bit;
+            if (code == 0u) b2 |= bit;
+            if (code != 1u) bv |= bit;
+        }
+    }
+    planes[(0 * m + mk) * w64 + w] = b1;
+    planes[(1 * m + mk) * w64 + w] = b2;
+    planes[(2 * m + mk) * w64 + w] = bv;
+}
+
+// tau-b -> sin(pi/2 tau) in the reference's fp32 operation order (corr_kernels.cu:544-564)
+__device__ __forceinline__ float npn_from_counts(const float *s)
+{
+    float p = ((s[0] * (s[4] + s[5] + s[7] + s[8])) + (s[1] * (s[5] + s[8])) + (s[3] * (s[7] + s[8])) + (s[4] * s[8]));
+    float q = ((s[1] * (s[3] + s[6])) + (s[2] * (s[3] + s[4] + s[6] + s[7])) + (s[4] * s[6]) + (s[5] * (s[6] + s[7])));
+    float t = ((s[0] * (s[1] + s[2])) + (s[1] * s[2]) + (s[3] * (s[4] + s[5])) + (s[4] * s[5]) + (s[6] * (s[7] + s[8])) +
+               (s[7] * s[8]));
+    float u = ((s[0] * (s[3] + s[6])) + (s[1] * (s[4] + s[7])) + (s[2] * (s[5] + s[8])) + (s[3] * s[6]) + (s[4] * s[7]) +
+               (s[5] * s[8]));
+    float kendall = (p - q) / sqrtf((p + q + t) * (p + q + u));
+    return (float)sin(M_PI / 2 * (double)kendall);
+}
+
+// counts for a 32 x 32 tile of marker pairs (upper triangle of tiles), 2 x 2 pairs per thread
+constexpr int kTile = 32;
+constexpr int kKW = 8;  // 64-bit words per staged K chunk
+__global__ void __launch_bounds__(256) mxm_popcount_kernel(const unsigned long long *__restrict__ planes, float *C,
+                                                            size_t m, size_t w64, size_t n, int tiles)
+{
+    __shared__ unsigned long long sa[3][kTile][kKW + 1];
+    __shared__ unsigned long long sb[3][kTile][kKW + 1];
+    int t = blockIdx.x, bi = 0;
+    {
+        int rem = t, len = tiles;
+        while (rem >= len)
+        {
+            rem -= len;
+            len--;
+            bi++;
+        }
+        t = bi + rem;
+    }
+    const int bj = t;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;  // pair sub-tile (2 rows x 2 cols)
+    unsigned cnt[2][2][9];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+#pragma unroll
+            for (int c = 0; c < 9; c++) cnt[a][b][c] = 0;
+
+    for (size_t w0 = 0; w0 < w64; w0 += kKW)
+    {
+        for (int e = threadIdx.x; e < 3 * kTile * kKW; e += 256)
+        {
+            const int pl = e / (kTile * kKW), r = (e / kKW) % kTile, k = e % kKW;
+            const size_t w = w0 + k;
+            const size_t ma = (size_t)bi * kTile + r, mb = (size_t)bj * kTile + r;
+            sa[pl][r][k] = (ma < m && w < w64) ? planes[((size_t)pl * m + ma) * w64 + w] : 0ull;
+            sb[pl][r][k] = (mb < m && w < w64) ? planes[((size_t)pl * m + mb) * w64 + w] : 0ull;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < kKW; k++)
+        {
+            unsigned long long a1[2], a2[2], av[2], b1[2], b2[2], bv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+            {
+                a1[u] = sa[0][ty * 2 + u][k];
+                a2[u] = sa[1][ty * 2 + u][k];
+                av[u] = sa[2][ty * 2 + u][k];
+                b1[u] = sb[0][tx * 2 + u][k];
+                b2[u] = sb[1][tx * 2 + u][k];
+                bv[u] = sb[2][tx * 2 + u][k];
+            }
+#pragma unroll
+            for (int a = 0; a < 2; a++)
+#pragma unroll
+                for (int b = 0; b < 2; b++)
+                {
+                    // raw products; the table cells are formed from them in the epilogue
+                    cnt[a][b][0] += __popcll(a1[a] & b1[b]);
+                    cnt[a][b][1] += __popcll(a1[a] & b2[b]);
+                    cnt[a][b][2] += __popcll(a2[a] & b1[b]);
+                    cnt[a][b][3] += __popcll(a2[a] & b2[b]);
+                    cnt[a][b][4] += __popcll(a1[a] & bv[b]);
+                    cnt[a][b][5] += __popcll(a2[a] & bv[b]);
+                    cnt[a][b][6] += __popcll(av[a] & b1[b]);
+                    cnt[a][b][7] += __popcll(av[a] & b2[b]);
+                    cnt[a][b][8] += __popcll(av[a] & bv[b]);
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+        {
+            const size_t i = (size_t)bi * kTile + ty * 2 + a, j = (size_t)bj * kTile + tx * 2 + b;
+            if (i < m && j < m && i < j)
+            {
+                const unsigned *c = cnt[a][b];
+                const unsigned n11 = c[0], n12 = c[1], n21 = c[2], n22 = c[3], n1v = c[4], n2v = c[5], nv1 = c[6],
+                               nv2 = c[7], nvv = c[8];
+                float s[9];
+                // s[3*va + vb], va/vb = genotype value of the row/column marker
+                s[4] = (float)n11;
+                s[5] = (float)n12;
+                s[7] = (float)n21;
+                s[8] = (float)n22;
+                s[3] = (float)(n1v - n11 - n12);
+                s[6] = (float)(n2v - n21 - n22);
+                s[1] = (float)(nv1 - n11 - n21);
+                s[2] = (float)(nv2 - n12 - n22);
+                s[0] = (float)(nvv - n1v - n2v - (nv1 - n11 - n21) - (nv2 - n12 - n22));
+                const float r = npn_from_counts(s);
+                C[i * n + j] = r;
+                C[j * n + i] = r;
+            }
+        }
+}
+
+// one wave per marker, all traits: Pearson of corr_kernels.cu:157-238
+constexpr int kMaxPhenRegs = 32;
+__global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restrict__ bed, const float *__restrict__ phen,
+                                                   const float *__restrict__ mean, const float *__restrict__ sd, float *C,
+                                                   float *mxp, size_t m, size_t N, size_t p, size_t clb, size_t n,
+                                                   size_t p0, size_t pcount)
+{
+    const size_t mk = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (mk >= m) return;
+    float sgy[kMaxPhenRegs], sy[kMaxPhenRegs], sn[kMaxPhenRegs];
+#pragma unroll
+    for (int k = 0; k < kMaxPhenRegs; k++) sgy[k] = sy[k] = sn[k] = 0.0f;
+    for (size_t bi = lane; bi < clb; bi += 64)
+    {
+        const unsigned v = bed[mk * clb + bi];
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const size_t smp = bi * 4 + j;
+            if (smp >= N) break;
+            const unsigned code = (v >> (2 * j)) & 3u;
+            const float valid = (code != 1u) ? 1.0f : 0.0f;
+            const float g = (code == 0u) ? 2.0f : ((code == 2u) ? 1.0f : 0.0f);
+#pragma unroll
+            for (int k = 0; k < kMaxPhenRegs; k++)
+            {
+                if ((size_t)k < pcount)
+                {
+                    const float y = phen[(p0 + k) * N + smp];
+                    if (!(y != y))
+                    {
+                        sgy[k] += valid * g * y;
+                        sy[k] += valid * y;
+                        sn[k] += valid;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPhenRegs; k++)
+    {
+        if ((size_t)k < pcount)
+        {
+            float a = sgy[k], b = sy[k], c = sn[k];
+            for (int o = 32; o > 0; o >>= 1)
+            {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+                c += __shfl_xor(c, o);
+            }
+            if (lane == 0)
+            {
+                const float r = (a - mean[mk] * b) / (c * sd[mk]);
+                const size_t t = p0 + k;
+                if (C)
+                {
+                    C[mk * n + m + t] = r;
+                    C[(m + t) * n + mk] = r;
+                }
+                if (mxp) mxp[mk * p + t] = r;
+            }
+        }
+    }
+}
+
+// one workgroup per trait pair (a < b): corr_kernels.cu:285-343
+__global__ void __launch_bounds__(256) pxp_kernel(const float *__restrict__ phen, float *C, size_t m, size_t N, size_t p,
+                                                   size_t n)
+{
+    __shared__ float ss[256], sc[256];
+    size_t lin = blockIdx.x, a = 0, len = p - 1;
+    while (lin >= len)
+    {
+        lin -= len;
+        len--;
+        a++;
+    }
+    const size_t b = a + 1 + lin;
+    float s = 0.0f, c = 0.0f;
+    for (size_t i = threadIdx.x; i < N; i += 256)
+    {
+        const float va = phen[a * N + i], vb = phen[b * N + i];
+        if (!((va != va) || (vb != vb)))
+        {
+            s += va * vb;
+            c += 1.0f;
+        }
+    }
+    ss[threadIdx.x] = s;
+    sc[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1)
+    {
+        if ((int)threadIdx.x < o)
+        {
+            ss[threadIdx.x] += ss[threadIdx.x + o];
+            sc[threadIdx.x] += sc[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+    {
+        const float r = ss[0] / sc[0];
+        C[(m + a) * n + m + b] = r;
+        C[(m + b) * n + m + a] = r;
+    }
+}
+
+__global__ void unit_diag_kernel(float *C, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) C[i * n + i] = 1.0f;
+}
+
+// upper triangle (without diagonal) of the rows/cols [lo, lo+cnt) of C into a linear array
+__global__ void extract_tri_kernel(const float *__restrict__ C, float *out, size_t lo, size_t cnt, size_t n)
+{
+    const size_t i = blockIdx.y;
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cnt || j >= cnt || j <= i) return;
+    const size_t lin = i * (cnt - 1) - (i * (i - 1)) / 2 + (j - i - 1);
+    out[lin] = C[(lo + i) * n + lo + j];
+}
+
+int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N, size_t p,
+                    const float *mean, const float *std, float *C_dev, float *mxp_host, float *mxm_tri_host,
+                    float *pxp_tri_host)
+{
+    if (!e || !bed || !phen || !mean || !std || m == 0 || N == 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t clb = (N + 3) / 4, w64 = (N + 63) / 64, n = m + p;
+    CUSK_HIP(e, e->bed_dev.ensure(m * clb));
+    CUSK_HIP(e, e->phen_dev.ensure(sizeof(float) * std::max<size_t>(p * N, 1)));
+    CUSK_HIP(e, e->mean_dev.ensure(sizeof(float) * m));
+    CUSK_HIP(e, e->std_dev.ensure(sizeof(float) * m));
+    CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
+    CUSK_HIP(e, hipEventRecord(e->ev[0], s));
+    CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
+    if (p) CUSK_HIP(e, hipMemcpyAsync(e->phen_dev.p, phen, sizeof(float) * p * N, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(e->mean_dev.p, mean, sizeof(float) * m, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(e->std_dev.p, std, sizeof(float) * m, hipMemcpyHostToDevice, s));
+    float *mxp_d = nullptr;
+    if (mxp_host && p)
+    {
+        CUSK_HIP(e, e->mxp_dev.ensure(sizeof(float) * m * p));
+        mxp_d = e->mxp_dev.as<float>();
+    }
+    CUSK_HIP(e, hipEventRecord(e->ev[1], s));
+    if (C_dev)
+    {
+        hipLaunchKernelGGL(bed_to_bitplanes_kernel, dim3((unsigned)((m * w64 + 255) / 256)), dim3(256), 0, s,
+                           e->bed_dev.as<unsigned char>(), e->planes.as<unsigned long long>(), m, N, clb, w64);
+        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
+        const int tiles = (int)((m + kTile - 1) / kTile);
+        const long long nt = (long long)tiles * (tiles + 1) / 2;
+        hipLaunchKernelGGL(mxm_popcount_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->planes.as<unsigned long long>(),
+                           C_dev, m, w64, n, tiles);
+        hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C_dev, n);
+    }
+    else
+    {
+        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
+    }
+    CUSK_HIP(e, hipEventRecord(e->ev[3], s));
+    for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
+    {
+        const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
+        hipLaunchKernelGGL(mxp_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
+                           e->phen_dev.as<float>(), e->mean_dev.as<float>(), e->std_dev.as<float>(), C_dev, mxp_d, m, N, p,
+                           clb, n, p0, pc);
+    }
+    if (C_dev && p > 1)
+        hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, e->phen_dev.as<float>(), C_dev, m,
+                           N, p, n);
+    CUSK_HIP(e, hipGetLastError());
+    CUSK_HIP(e, hipEventRecord(e->ev[4], s));
+    if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(mxp_host, mxp_d, sizeof(float) * m * p, hipMemcpyDeviceToHost, s));
+    if (C_dev && (mxm_tri_host || pxp_tri_host))
+    {
+        DevBuf tri;
+        const size_t cm = m * (m - 1) / 2, cp = p ? p * (p - 1) / 2 : 0;
+        CUSK_HIP(e, tri.ensure(sizeof(float) * std::max<size_t>(std::max(cm, cp), 1)));
+        if (mxm_tri_host && cm)
+        {
+            hipLaunchKernelGGL(extract_tri_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)m), dim3(256), 0, s, C_dev,
+                               tri.as<float>(), (size_t)0, m, n);
+            CUSK_HIP(e, hipMemcpyAsync(mxm_tri_host, tri.p, sizeof(float) * cm, hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+        }
+        if (pxp_tri_host && cp)
+        {
+            hipLaunchKernelGGL(extract_tri_kernel, dim3((unsigned)((p + 255) / 256), (unsigned)p), dim3(256), 0, s, C_dev,
+                               tri.as<float>(), m, p, n);
+            CUSK_HIP(e, hipMemcpyAsync(pxp_tri_host, tri.p, sizeof(float) * cp, hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+        }
+        tri.release();
+    }
+    CUSK_HIP(e, hipStreamSynchronize(s));
+    float ms = 0;
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[1], e->ev[2]));
+    e->corr_ms[0] = ms;
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
+    e->corr_ms[1] = ms;
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[3], e->ev[4]));
+    e->corr_ms[2] = ms;
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[4]));
+    e->corr_ms[3] = ms;
+    return CUSK_OK;
+}
+
+}  // namespace cusk
+
+using namespace cusk;
+
+extern "C" int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N, size_t p,
+                               const float *mean, const float *std, float *C_dev, float *mxp_host)
+{
+    return corr_build_impl(e, bed, phen, m, N, p, mean, std, C_dev, mxp_host, nullptr, nullptr);
+}
+
+extern "C" void cusk_corr_timing(const cusk_engine *e, float *ms4)
+{
+    for (int i = 0; i < 4; i++) ms4[i] = e ? e->corr_ms[i] : 0.0f;
+}
+
+namespace {
+cusk_engine *corr_engine()
+{
+    cusk_engine *e = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (cusk_engine_create(&e, dev, nullptr) != CUSK_OK)
+    {
+        std::fprintf(stderr, "libcusk_hip: cannot create engine (no HIP device?)\n");
+        std::exit(EXIT_FAILURE);
+    }
+    return e;
+}
+}  // namespace
+
+extern "C" void cu_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals,
+                                            const size_t num_markers, const size_t num_individuals,
+                                            const size_t num_phen, const float *marker_mean, const float *marker_std,
+                                            float *marker_phen_corrs)
+{
+    cusk_engine *e = corr_engine();
+    if (corr_build_impl(e, marker_vals, phen_vals, num_markers, num_individuals, num_phen, marker_mean, marker_std, nullptr,
+                        marker_phen_corrs, nullptr, nullptr) != CUSK_OK)
+    {
+        std::fprintf(stderr, "libcusk_hip: cu_marker_phen_corr_pearson: %s\n", cusk_last_error(e));
+        std::exit(EXIT_FAILURE);
+    }
+    cusk_engine_destroy(e);
+}
+
+extern "C" void cu_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                                    const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                                    const float *marker_std, float *marker_corrs, float *marker_phen_corrs,
+                                    float *phen_corrs)
+{
+    cusk_engine *e = corr_engine();
+    const size_t n = num_markers + num_phen;
+    float *Cd = static_cast<float *>(cusk_dev_alloc(sizeof(float) * n * n));
+    if (!Cd || corr_build_impl(e, marker_vals, phen_vals, num_markers, num_individuals, num_phen, marker_mean, marker_std, Cd,
+                               marker_phen_corrs, marker_corrs, phen_corrs) != CUSK_OK)
+    {
+        std::fprintf(stderr, "libcusk_hip: cu_corr_pearson_npn: %s\n", cusk_last_error(e));
+        std::exit(EXIT_FAILURE);
+    }
+    cusk_dev_free(Cd);
+    cusk_engine_destroy(e);
+}

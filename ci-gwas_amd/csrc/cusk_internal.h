@@ -1,0 +1,121 @@
+// cusk_internal.h -- engine state shared by the translation units of libcusk_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/cusk_hip.h"
+
+namespace cusk {
+
+constexpr int kML = CUSK_ML;
+constexpr unsigned long long kNone = ~0ull;
+// degree classes of the level sweep: rows whose (d+1)^2 sub-matrix fits the class
+// capacity are staged in LDS; the last class reads C from global memory.
+constexpr int kNumClasses = 5;
+constexpr int kClassCap[kNumClasses] = {31, 63, 127, 191, 1 << 30};
+constexpr int kThreads = 256;
+constexpr size_t kLdsLimit = 160 * 1024;
+
+struct DevBuf
+{
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes)
+    {
+        if (bytes <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T>
+    T *as() const
+    {
+        return reinterpret_cast<T *>(p);
+    }
+};
+
+// small block of device counters, mirrored into pinned host memory each level
+struct LevelCounters
+{
+    int maxdeg;
+    int pad0;
+    long long total_edges;
+    long long class_items[kNumClasses];
+    unsigned long long tests;
+    unsigned long long subsets;
+    unsigned long long removed;
+    unsigned long long nrec;
+    int overflow;
+    int pad1;
+};
+
+}  // namespace cusk
+
+struct cusk_engine
+{
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    // result / working state of the last run
+    int n = 0;
+    int words = 0;
+    int mode = -1;  // 0 Skeleton, 1 hetcor
+    bool have_result = false;
+    cusk::DevBuf adj, adj0;  // uint64 n*words: live adjacency, adjacency after level 0
+    cusk::DevBuf deg, off, nbr, best, rowinfo, binom, counters, ti;
+    cusk::DevBuf items[cusk::kNumClasses];
+    cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
+    long long nrec = 0;
+    long long rec_cap = 0;
+    cusk::LevelCounters *hcnt = nullptr;  // pinned
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+
+    // correlation build scratch
+    cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev;
+    float corr_ms[4] = {0, 0, 0, 0};
+};
+
+namespace cusk {
+
+inline int fail(cusk_engine *e, int code, const std::string &msg)
+{
+    if (e) e->err = msg;
+    return code;
+}
+
+#define CUSK_HIP(e, call)                                                                        \
+    do                                                                                           \
+    {                                                                                            \
+        hipError_t _st = (call);                                                                 \
+        if (_st != hipSuccess)                                                                   \
+            return cusk::fail((e), CUSK_ERR_HIP,                                                 \
+                              std::string(#call) + ": " + hipGetErrorString(_st) + " (" +        \
+                                  __FILE__ + ":" + std::to_string(__LINE__) + ")");              \
+    } while (0)
+
+// host-side helpers shared by the entry points
+void threshold_array_host(int n, float alpha, float *thr15);
+float hetcor_threshold_host(float alpha);
+
+// corr_build.hip
+int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N,
+                    size_t p, const float *mean, const float *std, float *C_dev, float *mxp_host,
+                    float *mxm_tri_host, float *pxp_tri_host);
+
+}  // namespace cusk

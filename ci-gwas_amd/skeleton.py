@@ -1,0 +1,219 @@
+"""Host-side mirror of the reference's operator interface for the cusk path.
+
+`Skeleton`, `hetcor_skeleton`, `threshold_array`, `hetcor_threshold`,
+`cu_corr_pearson_npn` and `cu_marker_phen_corr_pearson` take and return host
+numpy arrays with the reference's argument meaning
+(/root/reference/cusk/include/mps/cuPC-S.h:196, hetcor-cuPC-S.h:46,
+cuPC_call_prep.h:7-15, corr_host.h:38-47,92-103) and call straight through the
+C ABI of libcusk_hip.so.  `Engine` is the device-resident API used by bench.py
+and the mps host program (matrix stays in HBM, sparse sepsets).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._lib import ML, CuskStats, lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def threshold_array(n: int, alpha: float) -> np.ndarray:
+    out = np.zeros(ML + 1, np.float32)
+    lib().cusk_threshold_array(int(n), float(np.float32(alpha)), _ptr(out))
+    return out
+
+
+def hetcor_threshold(alpha: float) -> float:
+    return float(lib().cusk_hetcor_threshold(float(np.float32(alpha))))
+
+
+def Skeleton(Cm: np.ndarray, Th: np.ndarray, maxlevel: int, want_pmax: bool = True, want_sepset: bool = True):
+    """-> (G n*n int32, level, pMax n*n float32 | None, SepSet n*n*14 int32 | None)."""
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    n = Cm.shape[0]
+    G = np.ones((n, n), np.int32)
+    pmax = np.zeros((n, n), np.float32) if want_pmax else None
+    sep = np.zeros((n, n, ML), np.int32) if want_sepset else None
+    Th = np.ascontiguousarray(Th, np.float32)
+    P, l, ml = C.c_int(n), C.c_int(0), C.c_int(int(maxlevel))
+    lib().Skeleton(_ptr(Cm), C.addressof(P), _ptr(G), _ptr(Th), C.addressof(l), C.addressof(ml), _ptr(pmax), _ptr(sep))
+    return G, l.value, pmax, sep
+
+
+def hetcor_skeleton(Cm, G, N, th: float, maxlevel: int, time_index):
+    """-> (G n*n int32 (copy, updated), level)."""
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    n = Cm.shape[0]
+    G = np.array(G, np.int32).reshape(n, n).copy()
+    N = np.ascontiguousarray(N, np.float32).reshape(n, n)
+    ti = np.ascontiguousarray(time_index, np.int32)
+    P, l, ml, thv = C.c_int(n), C.c_int(0), C.c_int(int(maxlevel)), C.c_float(float(np.float32(th)))
+    lib().hetcor_skeleton(_ptr(Cm), C.addressof(P), _ptr(G), _ptr(N), C.addressof(thv), C.addressof(l), C.addressof(ml), _ptr(ti))
+    return G, l.value
+
+
+def cu_marker_phen_corr_pearson(bed, phen, m, N, p, means, stds) -> np.ndarray:
+    bed = np.ascontiguousarray(bed, np.uint8)
+    phen = np.ascontiguousarray(phen, np.float32)
+    means = np.ascontiguousarray(means, np.float32)
+    stds = np.ascontiguousarray(stds, np.float32)
+    out = np.zeros(m * p, np.float32)
+    lib().cu_marker_phen_corr_pearson(_ptr(bed), _ptr(phen), m, N, p, _ptr(means), _ptr(stds), _ptr(out))
+    return out
+
+
+def cu_corr_pearson_npn(bed, phen, m, N, p, means, stds):
+    bed = np.ascontiguousarray(bed, np.uint8)
+    phen = np.ascontiguousarray(phen, np.float32)
+    means = np.ascontiguousarray(means, np.float32)
+    stds = np.ascontiguousarray(stds, np.float32)
+    mxm = np.zeros(max(m * (m - 1) // 2, 1), np.float32)
+    mxp = np.zeros(max(m * p, 1), np.float32)
+    pxp = np.zeros(max(p * (p - 1) // 2, 1), np.float32)
+    lib().cu_corr_pearson_npn(_ptr(bed), _ptr(phen), m, N, p, _ptr(means), _ptr(stds), _ptr(mxm), _ptr(mxp), _ptr(pxp))
+    return mxm[: m * (m - 1) // 2], mxp[: m * p], pxp[: p * (p - 1) // 2]
+
+
+@dataclass
+class Stats:
+    level: int
+    levels_run: int
+    max_degree: list
+    edges: list
+    tests: list
+    subsets: list
+    removed: list
+    kernel_ms: list
+    level_ms: list
+    total_ms: float
+
+    @staticmethod
+    def of(s: CuskStats) -> "Stats":
+        return Stats(s.level, s.levels_run, list(s.max_degree), list(s.edges), list(s.tests), list(s.subsets),
+                     list(s.removed), list(s.kernel_ms), list(s.level_ms), float(s.total_ms))
+
+
+class DeviceArray:
+    """n-byte HBM allocation owned by the library (no torch needed)."""
+
+    def __init__(self, host: np.ndarray | None = None, nbytes: int | None = None):
+        self.nbytes = int(host.nbytes if host is not None else nbytes)
+        self.ptr = lib().cusk_dev_alloc(self.nbytes)
+        if not self.ptr:
+            raise MemoryError(f"cusk_dev_alloc({self.nbytes}) failed")
+        if host is not None:
+            h = np.ascontiguousarray(host)
+            if lib().cusk_dev_upload(self.ptr, _ptr(h), h.nbytes) != 0:
+                raise RuntimeError("upload failed")
+
+    def download(self, dtype, shape) -> np.ndarray:
+        out = np.empty(shape, dtype)
+        if lib().cusk_dev_download(_ptr(out), self.ptr, out.nbytes) != 0:
+            raise RuntimeError("download failed")
+        return out
+
+    def free(self):
+        if self.ptr:
+            lib().cusk_dev_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """Device-resident engine (cusk_engine_* of include/cusk_hip.h)."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        rc = lib().cusk_engine_create(C.byref(h), int(device), C.c_void_p(stream) if stream else None)
+        if rc != 0:
+            raise RuntimeError(f"cusk_engine_create failed with code {rc} (no MI355X / HIP device?)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            lib().cusk_engine_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"libcusk_hip error {rc}: {lib().cusk_last_error(self.h).decode()}")
+
+    @property
+    def stream(self) -> int:
+        return int(lib().cusk_engine_stream(self.h) or 0)
+
+    def run_skeleton(self, C_dev: int, n: int, Th, maxlevel: int) -> Stats:
+        Th = np.ascontiguousarray(Th, np.float32)
+        st = CuskStats()
+        self._check(lib().cusk_run_skeleton(self.h, C_dev, n, _ptr(Th), int(maxlevel), C.byref(st)))
+        return Stats.of(st)
+
+    def run_hetcor(self, C_dev: int, n: int, th: float, maxlevel: int, N_dev: int | None = None,
+                   ess_uniform: float = 0.0, G_init_dev: int | None = None, time_index=None) -> Stats:
+        ti = np.ascontiguousarray(time_index, np.int32) if time_index is not None else None
+        st = CuskStats()
+        self._check(lib().cusk_run_hetcor(self.h, C_dev, N_dev, float(ess_uniform), G_init_dev, n,
+                                          float(np.float32(th)), int(maxlevel), _ptr(ti), C.byref(st)))
+        return Stats.of(st)
+
+    def adjacency(self) -> np.ndarray:
+        n = lib().cusk_result_n(self.h)
+        G = np.zeros((n, n), np.int32)
+        self._check(lib().cusk_result_adj_i32(self.h, _ptr(G)))
+        return G
+
+    def adjacency_bits(self) -> np.ndarray:
+        n, w = lib().cusk_result_n(self.h), lib().cusk_result_words(self.h)
+        out = np.zeros((n, w), np.uint64)
+        self._check(lib().cusk_dev_download(_ptr(out), lib().cusk_result_adj_bits_dev(self.h), out.nbytes))
+        return out
+
+    def pmax(self, C_dev: int) -> np.ndarray:
+        n = lib().cusk_result_n(self.h)
+        out = np.zeros((n, n), np.float32)
+        self._check(lib().cusk_result_pmax(self.h, C_dev, _ptr(out)))
+        return out
+
+    def sepsets(self):
+        """-> (x, y, level, z, S[count,14]) sparse records, sorted by (x, y)."""
+        cnt = lib().cusk_result_sepsets(self.h, None, None, None, None, None)
+        if cnt < 0:
+            raise RuntimeError("no Skeleton result")
+        x, y, lv = (np.zeros(cnt, np.int32) for _ in range(3))
+        z = np.zeros(cnt, np.float32)
+        S = np.full((cnt, ML), -1, np.int32)
+        if cnt:
+            lib().cusk_result_sepsets(self.h, _ptr(x), _ptr(y), _ptr(lv), _ptr(z), _ptr(S))
+            o = np.lexsort((y, x))
+            x, y, lv, z, S = x[o], y[o], lv[o], z[o], S[o]
+        return x, y, lv, z, S
+
+    def corr_build(self, bed, phen, m, N, p, means, stds, C_dev: int, want_mxp: bool = False):
+        bed = np.ascontiguousarray(bed, np.uint8)
+        phen = np.ascontiguousarray(phen, np.float32)
+        means = np.ascontiguousarray(means, np.float32)
+        stds = np.ascontiguousarray(stds, np.float32)
+        mxp = np.zeros(m * p, np.float32) if want_mxp else None
+        self._check(lib().cusk_corr_build(self.h, _ptr(bed), _ptr(phen), m, N, p, _ptr(means), _ptr(stds), C_dev, _ptr(mxp)))
+        return mxp
+
+    def corr_timing(self):
+        t = np.zeros(4, np.float32)
+        lib().cusk_corr_timing(self.h, _ptr(t))
+        return t

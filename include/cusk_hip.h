@@ -1,0 +1,162 @@
+/*
+ * cusk_hip.h -- C ABI of libcusk_hip.so, the MI355X-native `cusk` PC-skeleton engine.
+ *
+ * Plain pointers and sizes only.  Two groups of entry points:
+ *
+ *  (1) the reference's own operator interface for this path, with identical
+ *      names, argument order and argument meaning, so that the reference's
+ *      callers (cusk/src/cli.cpp:45,72,550,581,670) link against this library
+ *      unchanged -- host buffers in, host buffers out, blocking;
+ *  (2) a device-resident engine API (cusk_*) that the `mps` host program and
+ *      bench.py use: matrices stay in HBM between the correlation build and
+ *      the level sweep, adjacency is a bitmap, separation sets are sparse.
+ *
+ * Citations are to /root/reference/cusk.
+ */
+#ifndef CUSK_HIP_H_
+#define CUSK_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CUSK_ML 14 /* include/mps/cuPC-S.h:49 (ML) */
+
+/* ---------------------------------------------------------------------------
+ * (1) reference-compatible entry points
+ * ------------------------------------------------------------------------ */
+
+/* Replaces `extern "C" void Skeleton(...)`, include/mps/cuPC-S.h:196-198,
+ * src/cuPC-S.cu:61-450.  All pointers are caller-owned HOST memory.
+ *   C        in   n*n fp32 row-major correlation matrix
+ *   P        in   *P = n
+ *   G        out  n*n int32 adjacency (fully overwritten)
+ *   Th       in   thresholds Th[0..min(14,*maxlevel)]
+ *   l        out  level counter as the reference leaves it
+ *   maxlevel in   maximal conditioning-set size (<= 14)
+ *   pMax     out  n*n fp32: -100000 on surviving edges, max Fisher z of the
+ *                 two directions on removed ones, 1 on the diagonal
+ *   SepSet   out  n*n*14 int32, -1 padded
+ * Errors (HIP failure, combinatorial overflow): message on stderr, exit(EXIT_FAILURE),
+ * as include/mps/gpuerrors.h:6-15 does. */
+void Skeleton(float *C, int *P, int *G, float *Th, int *l, const int *maxlevel, float *pMax,
+              int *SepSet);
+
+/* Replaces `extern "C" void hetcor_skeleton(...)`, include/mps/hetcor-cuPC-S.h:46,
+ * src/hetcor-cuPC-S.cu:75-341.  G is IN/OUT (zeros are respected, level 0 only
+ * removes), N is the n*n effective-sample-size matrix, *Th the single
+ * alpha/2 quantile, time_index has n entries (markers 0). */
+void hetcor_skeleton(float *C, int *P, int *G, float *N, float *Th, int *l, const int *maxlevel,
+                     const int *time_index);
+
+/* Replaces threshold_array / hetcor_threshold, include/mps/cuPC_call_prep.h:7-15,
+ * src/cuPC_call_prep.cpp:13-27 (the reference returns std::vector<float>; here
+ * the caller passes room for 15 floats). */
+void cusk_threshold_array(int n, float alpha, float *thr15);
+float cusk_hetcor_threshold(float alpha);
+
+/* Replace cu_marker_phen_corr_pearson / cu_corr_pearson_npn,
+ * include/mps/corr_host.h:38-47,92-103, src/corr_host.cu:1023-1197.  Host
+ * buffers; marker_vals is SNP-major packed .bed without the 3 magic bytes,
+ * phen_vals column-major with NaN = missing.  Outputs: marker_corrs upper
+ * triangle without diagonal (row-major linear), marker_phen_corrs m*p
+ * row-major, phen_corrs upper triangle without diagonal. */
+void cu_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals,
+                                 const size_t num_markers, const size_t num_individuals,
+                                 const size_t num_phen, const float *marker_mean,
+                                 const float *marker_std, float *marker_phen_corrs);
+void cu_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals,
+                         const size_t num_markers, const size_t num_individuals,
+                         const size_t num_phen, const float *marker_mean, const float *marker_std,
+                         float *marker_corrs, float *marker_phen_corrs, float *phen_corrs);
+
+/* ---------------------------------------------------------------------------
+ * (2) device-resident engine
+ * ------------------------------------------------------------------------ */
+
+typedef struct cusk_engine cusk_engine;
+
+enum {
+    CUSK_OK = 0,
+    CUSK_ERR_HIP = 1,      /* a HIP runtime call failed */
+    CUSK_ERR_ARG = 2,      /* bad argument */
+    CUSK_ERR_OVERFLOW = 3, /* C(degree, level) does not fit 62 bits */
+    CUSK_ERR_STATE = 4     /* call order (no result to fetch, ...) */
+};
+
+/* per-run counters; index = level */
+typedef struct cusk_stats {
+    int level;                        /* what the reference leaves in *l */
+    int levels_run;                   /* number of levels that launched tests (incl. level 0) */
+    int max_degree[CUSK_ML + 1];      /* max degree at the start of the level (level 0: n-1) */
+    long long edges[CUSK_ML + 1];     /* directed edges at the start of the level */
+    long long tests[CUSK_ML + 1];     /* CI tests evaluated (SURVEY.md 8d definition) */
+    long long subsets[CUSK_ML + 1];   /* conditioning sets whose inverse was formed */
+    long long removed[CUSK_ML + 1];   /* ordered pairs (X,Y) for which a separating set was found */
+    float kernel_ms[CUSK_ML + 1];     /* HIP-event time of the level's sweep kernels */
+    float level_ms[CUSK_ML + 1];      /* HIP-event time of the whole level (compaction + sweep + finalise) */
+    float total_ms;                   /* whole run, events on the engine stream */
+} cusk_stats;
+
+/* device = HIP device ordinal; stream = a hipStream_t to run on, or NULL for a
+ * private non-blocking stream.  Returns CUSK_OK or an error code. */
+int cusk_engine_create(cusk_engine **out, int device, void *stream);
+void cusk_engine_destroy(cusk_engine *e);
+const char *cusk_last_error(const cusk_engine *e);
+void *cusk_engine_stream(const cusk_engine *e);
+
+/* Level sweep on a matrix already resident in HBM (C_dev: n*n fp32 row-major).
+ * cusk_run_skeleton   : `Skeleton` semantics (fixed per-level thresholds Th[0..14] on
+ *                       the host, sepsets + pMax recorded sparsely).
+ * cusk_run_hetcor     : `hetcor_skeleton` semantics.  N_dev may be NULL when every
+ *                       pair has the same effective sample size `ess_uniform`;
+ *                       G_init_dev (n*n int32, device) may be NULL for the
+ *                       complete graph; time_index is a HOST array of n ints or
+ *                       NULL (all zero).
+ * Both are asynchronous with respect to other streams but return after the
+ * level loop has finished (the loop needs the max degree on the host each level). */
+int cusk_run_skeleton(cusk_engine *e, const float *C_dev, int n, const float *Th, int maxlevel,
+                      cusk_stats *stats);
+int cusk_run_hetcor(cusk_engine *e, const float *C_dev, const float *N_dev, float ess_uniform,
+                    const int *G_init_dev, int n, float th, int maxlevel, const int *time_index,
+                    cusk_stats *stats);
+
+/* Results of the last run (valid until the next run / destroy). */
+int cusk_result_n(const cusk_engine *e);
+/* adjacency bitmap on the device: n rows of cusk_result_words() uint64 words, bit j of row i */
+const uint64_t *cusk_result_adj_bits_dev(const cusk_engine *e);
+int cusk_result_words(const cusk_engine *e);
+/* expand into the reference's layouts; dst is HOST memory unless the name says _dev */
+int cusk_result_adj_i32(cusk_engine *e, int *G_host);
+int cusk_result_adj_i32_dev(cusk_engine *e, int *G_dev);
+int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_host);
+int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host /* n*n*14 */);
+/* sparse separation sets: one record per ordered pair with a non-empty set.
+ * Returns the count; arrays may be NULL to query it.  x,y: count ints;
+ * level: count ints; z: count floats; S: count*14 ints (-1 padded). */
+long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *level, float *z, int *S);
+
+/* Correlation build on the device (a2-a5).  bed/phen/mean/std
+ * are HOST buffers as in cu_corr_pearson_npn; the n*n (n = m + p) square
+ * matrix (markers first, then traits, unit diagonal, symmetric;
+ * src/cli.cpp:597-649) is written to C_dev.  If mxp_host is not NULL it also
+ * receives the m*p marker-trait correlations (for the prefilter, cli.cpp:561-576). */
+int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m,
+                    size_t N, size_t p, const float *mean, const float *std, float *C_dev,
+                    float *mxp_host);
+/* timing of the last cusk_corr_build: [0] decode, [1] count GEMM, [2] mxp/pxp, [3] total (ms) */
+void cusk_corr_timing(const cusk_engine *e, float *ms4);
+
+/* device memory helpers so that C hosts need no HIP headers */
+void *cusk_dev_alloc(size_t bytes);
+void cusk_dev_free(void *p);
+int cusk_dev_upload(void *dst_dev, const void *src_host, size_t bytes);
+int cusk_dev_download(void *dst_host, const void *src_dev, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CUSK_HIP_H_ */

@@ -1,0 +1,215 @@
+"""GPU parity: the HIP engine (through the C ABI) vs the CPU oracle on the same inputs.
+
+Bars: adjacency, level counter and separation-set indices bit-exact; Fisher z / pMax
+within 1e-6 (north_star); SNP x SNP correlations bit-exact (integer counts + identical
+epilogue), SNP x trait and trait x trait within 1e-5 (the reference's own test tolerance,
+tests/corr_tests.cpp)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ML = 14
+
+
+@pytest.fixture(scope="module")
+def cg():
+    import cigwas_amd
+
+    return cigwas_amd
+
+
+@pytest.fixture(scope="module")
+def eng(cg):
+    e = cg.Engine(0)
+    yield e
+    e.close()
+
+
+def _dense_sepsets(n, x, y, S):
+    d = np.full((n, n, ML), -1, np.int32)
+    d[x, y] = S
+    return d
+
+
+def _check_skeleton(cg, eng, oracle, Cm, Th, maxlevel):
+    n = Cm.shape[0]
+    ref = oracle.skeleton(Cm, Th, maxlevel)
+    Cd = cg.DeviceArray(Cm)
+    st = eng.run_skeleton(Cd.ptr, n, Th, maxlevel)
+    G = eng.adjacency()
+    assert st.level == ref.level
+    assert np.array_equal(G, ref.G)
+    x, y, lv, z, S = eng.sepsets()
+    assert np.array_equal(_dense_sepsets(n, x, y, S), ref.sepset)
+    pm = eng.pmax(Cd.ptr)
+    assert np.allclose(pm, ref.pmax, rtol=0, atol=1e-6)
+    # the engine may evaluate more tests than the sequential schedule (parallel lanes), never fewer removals
+    for l in range(1, ML + 1):
+        assert st.tests[l] >= ref.tests[l] or st.tests[l] == 0 == ref.tests[l]
+    Cd.free()
+    return st, ref
+
+
+def test_kat_n10_compat_abi(cg, oracle, kat):
+    c = kat["cupc_n10"]
+    n = c["n"]
+    Cm = np.array(c["C"], np.float32).reshape(n, n)
+    Th = cg.threshold_array(c["sample_size"], c["alpha"])
+    G, level, pmax, sep = cg.Skeleton(Cm, Th, c["max_level"])
+    assert list(G.ravel()) == c["A"]
+    ref = oracle.skeleton(Cm, Th, c["max_level"])
+    assert level == ref.level and np.array_equal(sep, ref.sepset)
+    assert np.allclose(pmax, ref.pmax, rtol=0, atol=1e-6)
+    N = np.full((n, n), c["sample_size"], np.float32)
+    G2, level2 = cg.hetcor_skeleton(Cm, np.ones((n, n), np.int32), N, cg.hetcor_threshold(c["alpha"]), c["max_level"],
+                                    np.zeros(n, np.int32))
+    assert list(G2.ravel()) == c["A"]
+
+
+@pytest.mark.parametrize("n,seed,maxlevel", [(12, 1, 14), (24, 2, 14), (40, 3, 6), (64, 4, 4), (90, 5, 3)])
+def test_skeleton_random_sem(cg, eng, oracle, synth, n, seed, maxlevel):
+    Cm = synth.random_corr(n, seed=seed, k=6 * n)
+    Th = cg.threshold_array(6 * n, 0.01)
+    _check_skeleton(cg, eng, oracle, Cm, Th, maxlevel)
+
+
+def test_skeleton_dense_high_levels(cg, eng, oracle, synth):
+    """few samples -> many surviving edges -> exercises the SVD inverse up to l = 8"""
+    Cm = synth.random_corr(18, seed=11, k=400, strength=1.3)
+    Th = cg.threshold_array(400, 0.2)
+    st, ref = _check_skeleton(cg, eng, oracle, Cm, Th, 8)
+    assert st.level >= 5
+
+
+@pytest.mark.parametrize("m,p,maxlevel", [(400, 6, 3), (800, 10, 5)])
+def test_skeleton_ld_block(cg, eng, oracle, synth, m, p, maxlevel):
+    Cm = synth.synth_corr_block(m, p, N=4096, block_index=m)
+    Th = cg.threshold_array(4096, 1e-4)
+    st, ref = _check_skeleton(cg, eng, oracle, Cm, Th, maxlevel)
+    assert sum(st.removed[1:]) > 0
+
+
+@pytest.mark.parametrize("m,p,maxlevel", [(400, 6, 3), (800, 10, 5)])
+def test_hetcor_uniform_ess(cg, eng, oracle, synth, m, p, maxlevel):
+    Cm = synth.synth_corr_block(m, p, N=4096, block_index=m + 1)
+    n = m + p
+    th = cg.hetcor_threshold(1e-4)
+    ti = np.zeros(n, np.int32)
+    ti[m:] = 1
+    ref = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), 4096, np.float32), th, maxlevel, ti)
+    Cd = cg.DeviceArray(Cm)
+    st = eng.run_hetcor(Cd.ptr, n, th, maxlevel, ess_uniform=4096.0, time_index=ti)
+    assert st.level == ref.level
+    assert np.array_equal(eng.adjacency(), ref.G)
+    Cd.free()
+
+
+def test_hetcor_heterogeneous_ess_time_index_and_ginit(cg, eng, oracle, synth):
+    rng = np.random.default_rng(5)
+    m, p = 300, 8
+    n = m + p
+    Cm = synth.synth_corr_block(m, p, N=4096, block_index=77)
+    N = np.full((n, n), 4096, np.float32)
+    e = rng.uniform(0.5, 1.0, (n, p)).astype(np.float32) * np.float32(4096)
+    N[:, m:] = e
+    N[m:, :] = e.T
+    N[m:, m:] = np.maximum(N[m:, m:], N[m:, m:].T)
+    N[3, m + 1] = N[m + 1, 3] = np.nan  # NA correlation -> r = 0, ESS NaN
+    Cm[3, m + 1] = Cm[m + 1, 3] = 0.0
+    ti = np.zeros(n, np.int32)
+    ti[m:] = rng.integers(1, 4, p)
+    G0 = np.ones((n, n), np.int32)
+    G0[5, :] = 0
+    G0[:, 5] = 0  # a variable removed by an earlier stage
+    th = cg.hetcor_threshold(1e-4)
+    ref = oracle.hetcor_skeleton(Cm, G0, N, th, 4, ti)
+    G, level = cg.hetcor_skeleton(Cm, G0, N, th, 4, ti)  # compat ABI (host buffers)
+    assert level == ref.level and np.array_equal(G, ref.G)
+    Cd, Nd, Gd = cg.DeviceArray(Cm), cg.DeviceArray(N), cg.DeviceArray(G0)
+    st = eng.run_hetcor(Cd.ptr, n, th, 4, N_dev=Nd.ptr, G_init_dev=Gd.ptr, time_index=ti)
+    assert st.level == ref.level and np.array_equal(eng.adjacency(), ref.G)
+    for d in (Cd, Nd, Gd):
+        d.free()
+
+
+def test_hub_row_beyond_lds(cg, eng, oracle):
+    """one trait correlated with 260 markers: degree > 191 takes the unstaged path"""
+    rng = np.random.default_rng(9)
+    k, N = 260, 20000
+    X = rng.standard_normal((k, N))
+    y = 0.12 * X.sum(0) + rng.standard_normal(N)
+    z = 0.5 * y + rng.standard_normal(N)
+    Cm = np.corrcoef(np.vstack([X, y, z])).astype(np.float32)
+    Cm = np.triu(Cm, 1) + np.triu(Cm, 1).T
+    np.fill_diagonal(Cm, 1)
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    Th = cg.threshold_array(N, 0.01)
+    st, ref = _check_skeleton(cg, eng, oracle, Cm, Th, 2)
+    assert st.max_degree[1] > 191
+    n = Cm.shape[0]
+    th = cg.hetcor_threshold(0.01)
+    ref2 = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), N, np.float32), th, 2, np.zeros(n, np.int32))
+    Cd = cg.DeviceArray(Cm)
+    eng.run_hetcor(Cd.ptr, n, th, 2, ess_uniform=float(N))
+    assert np.array_equal(eng.adjacency(), ref2.G)
+    Cd.free()
+
+
+def test_edge_cases(cg, eng, oracle):
+    # n = 2, no edge survives level 0; and an identity matrix
+    for Cm in [np.array([[1, 0.001], [0.001, 1]], np.float32), np.eye(5, dtype=np.float32)]:
+        Th = cg.threshold_array(1000, 0.01)
+        G, level, pmax, sep = cg.Skeleton(Cm, Th, 3)
+        ref = oracle.skeleton(Cm, Th, 3)
+        assert np.array_equal(G, ref.G) and level == ref.level
+        assert np.allclose(pmax, ref.pmax, atol=1e-6) and np.array_equal(sep, ref.sepset)
+    # perfectly collinear pair: singular conditioning sets give NaN z and keep the edge
+    rng = np.random.default_rng(2)
+    X = rng.standard_normal((6, 200))
+    X[1] = X[0]
+    Cm = np.corrcoef(X).astype(np.float32)
+    np.fill_diagonal(Cm, 1)
+    Cm = np.ascontiguousarray((Cm + Cm.T) / 2, np.float32)
+    Th = cg.threshold_array(200, 0.3)
+    G, level, pmax, sep = cg.Skeleton(Cm, Th, 4)
+    ref = oracle.skeleton(Cm, Th, 4)
+    assert np.array_equal(G, ref.G) and level == ref.level and np.array_equal(sep, ref.sepset)
+    # maxlevel 0
+    G, level, _, _ = cg.Skeleton(Cm, Th, 0)
+    ref = oracle.skeleton(Cm, Th, 0)
+    assert np.array_equal(G, ref.G) and level == ref.level
+
+
+# ---------------------------------------------------------------- correlation build
+def test_corr_kat_bmt(cg, kat):
+    for key, mm, mp, pp in [("bmt", "exp_mxm", "exp_mxp", "exp_pxp"), ("bmt2", "exp_mxm_npn", "exp_mxp_pearson", "exp_pxp")]:
+        b = kat[key]
+        mxm, mxp, pxp = cg.cu_corr_pearson_npn(np.array(b["marker_vals"], np.uint8), np.array(b["phen_vals"], np.float32),
+                                               b["num_markers"], b["num_individuals"], b["num_phen"], b["marker_mean"],
+                                               b["marker_std"])
+        assert np.allclose(mxm, b[mm], atol=b["tol"], rtol=0)
+        assert np.allclose(mxp, b[mp], atol=b["tol"], rtol=0)
+        assert np.allclose(pxp, b[pp], atol=b["tol"], rtol=0)
+        mxp2 = cg.cu_marker_phen_corr_pearson(np.array(b["marker_vals"], np.uint8), np.array(b["phen_vals"], np.float32),
+                                              b["num_markers"], b["num_individuals"], b["num_phen"], b["marker_mean"],
+                                              b["marker_std"])
+        assert np.allclose(mxp2, b[mp], atol=b["tol"], rtol=0)
+
+
+@pytest.mark.parametrize("m,N,p", [(97, 1001, 3), (300, 2048, 7), (64, 130, 1)])
+def test_corr_build_vs_oracle(cg, eng, oracle, synth, m, N, p):
+    bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=m, miss=0.01)
+    phen = phen.copy()
+    phen[::97] = np.nan  # missing phenotypes
+    o_mxm, o_mxp, o_pxp = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
+    mxm, mxp, pxp = cg.cu_corr_pearson_npn(bed, phen, m, N, p, means, stds)
+    assert np.array_equal(mxm, o_mxm, equal_nan=True)  # exact counts, same epilogue
+    assert np.allclose(mxp, o_mxp, atol=1e-5, rtol=0)
+    assert np.allclose(pxp, o_pxp, atol=1e-5, rtol=0)
+    n = m + p
+    Cd = cg.DeviceArray(nbytes=4 * n * n)
+    mxp3 = eng.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr, want_mxp=True)
+    sq = Cd.download(np.float32, (n, n))
+    want = oracle.square_from_cusk_corrs(mxm, mxp, pxp, m, p)
+    assert np.array_equal(sq, want, equal_nan=True) and np.array_equal(mxp3, mxp)
+    Cd.free()
