@@ -81,9 +81,15 @@ def pack_bed(G: np.ndarray) -> np.ndarray:
 
 def bed_stats(G: np.ndarray):
     """per-marker mean and population std over non-missing samples (reference prep.cpp:56-73)."""
-    g = G.astype(np.float64)
-    g[G < 0] = np.nan
-    return np.nanmean(g, axis=1).astype(np.float32), np.nanstd(g, axis=1).astype(np.float32)
+    m = G.shape[0]
+    mean = np.empty(m, np.float32)
+    std = np.empty(m, np.float32)
+    for r0 in range(0, m, 512):
+        g = G[r0:r0 + 512].astype(np.float64)
+        g[g < 0] = np.nan
+        mean[r0:r0 + 512] = np.nanmean(g, axis=1)
+        std[r0:r0 + 512] = np.nanstd(g, axis=1)
+    return mean, std
 
 
 def synth_bed_block(m: int, N: int, p: int, block_index: int = 0, **kw):
