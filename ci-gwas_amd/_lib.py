@@ -22,6 +22,9 @@ class CuskStats(C.Structure):
         ("kernel_ms", C.c_float * (ML + 1)),
         ("level_ms", C.c_float * (ML + 1)),
         ("total_ms", C.c_float),
+        ("rechecks", C.c_longlong * (ML + 1)),
+        ("violations", C.c_longlong),
+        ("exact_fallbacks", C.c_longlong),
     ]
 
 
@@ -37,6 +40,7 @@ SYMBOLS = {
     "cusk_engine_create": (_i, [C.POINTER(_vp), _i, _vp]),
     "cusk_engine_destroy": (None, [_vp]),
     "cusk_last_error": (C.c_char_p, [_vp]),
+    "cusk_engine_set_option": (_i, [_vp, C.c_char_p, _ll]),
     "cusk_engine_stream": (_vp, [_vp]),
     "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),

@@ -26,6 +26,7 @@
 #include <cstring>
 
 #include "ci_exact.h"
+#include "ci_fast.h"
 #include "cusk_internal.h"
 
 namespace cusk {
@@ -251,6 +252,13 @@ __global__ void fill_u64_kernel(unsigned long long *p, size_t count, unsigned lo
 // the sweep
 // ---------------------------------------------------------------------------
 
+struct RecheckEntry
+{
+    int x;
+    int k2;
+    unsigned long long rank;
+};
+
 struct SweepParams
 {
     const float *C;
@@ -268,6 +276,10 @@ struct SweepParams
     unsigned long long chunk;
     int cap;  // class capacity (LDS carve), ignored when !STAGED
     LevelCounters *cnt;
+    // fast path (ci_fast.h)
+    float t2;                  // tanh(th)^2 for fixed-threshold modes
+    RecheckEntry *queue;       // tests that need the exact path
+    unsigned long long qcap;
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -539,6 +551,373 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
     }
 }
 
+
+// unrank a 0-based lexicographic combination rank into ascending positions idx[0..L) out of d
+template <int L>
+__device__ __forceinline__ void unrank_comb(unsigned long long rem, int d, const unsigned long long *__restrict__ binom,
+                                            int *idx)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        while (true)
+        {
+            unsigned long long b = binom[(size_t)(d - 1 - c) * (L + 1) + (L - 1 - i)];
+            if (rem < b) break;
+            rem -= b;
+            c++;
+        }
+        idx[i] = c;
+        c++;
+    }
+}
+
+// Fast sweep for L >= 2 (ci_fast.h): same tiling, staging, lane <-> conditioning-set mapping and
+// selection rule as sweep_kernel, but every test is first judged by the register-Cholesky
+// filter; only uncertain ones are queued for the exact path.  VALIDATE additionally runs the
+// exact arithmetic on every certain verdict and counts disagreements (must stay 0).
+template <int L, int MODE, bool HET, bool STAGED, bool VALIDATE>
+__global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
+{
+    static_assert(L >= 2, "level 1 has its own kernels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[4];
+
+    const int2 item = p.items[blockIdx.x];
+    const int X = item.x;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    const int ld = (d + 1) | 1;
+
+    const LdsLayout lay = lds_layout(STAGED ? p.cap : 0, HET);
+    int *s_nbr = reinterpret_cast<int *>(smem + lay.nbr);
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(smem + lay.best);
+    int *s_ti = reinterpret_cast<int *>(smem + lay.ti);
+    float *s_sub = reinterpret_cast<float *>(smem + lay.sub);
+    float *s_ess = reinterpret_cast<float *>(smem + lay.ess);
+    const int *g_nbr = p.nbr + o0;
+
+    if (tid < 4) s_cnt[tid] = 0ull;
+    if constexpr (STAGED)
+    {
+        for (int k = tid; k <= d; k += kThreads)
+        {
+            int v = (k < d) ? g_nbr[k] : X;
+            s_nbr[k] = v;
+            if constexpr (MODE == 1) s_ti[k] = p.time_index[v];
+        }
+        for (int k = tid; k < d; k += kThreads)
+        {
+            if constexpr (MODE == 0)
+                s_best[k] = p.best[o0 + k];
+            else
+            {
+                int y = g_nbr[k];
+                unsigned long long wv = p.adj[(size_t)X * p.words + (y >> 6)];
+                s_best[k] = ((wv >> (y & 63)) & 1ull) ? kNone : 0ull;
+            }
+        }
+        __syncthreads();
+        const int dd = d + 1;
+        for (int e = tid; e < dd * dd; e += kThreads)
+        {
+            int i = e / dd, j = e - i * dd;
+            size_t g = (size_t)s_nbr[i] * n + s_nbr[j];
+            s_sub[i * ld + j] = p.C[g];
+            if constexpr (HET) s_ess[i * ld + j] = p.Ness[g];
+        }
+    }
+    __syncthreads();
+
+    auto var_of = [&](int i) -> int {
+        if constexpr (STAGED)
+            return s_nbr[i];
+        else
+            return (i < d) ? g_nbr[i] : X;
+    };
+    auto cval = [&](int i, int j) -> float {
+        if constexpr (STAGED)
+            return s_sub[i * ld + j];
+        else
+            return p.C[(size_t)var_of(i) * n + var_of(j)];
+    };
+    auto eval = [&](int i, int j) -> float {
+        if constexpr (STAGED)
+            return s_ess[i * ld + j];
+        else
+            return p.Ness[(size_t)var_of(i) * n + var_of(j)];
+    };
+    auto tix = [&](int i) -> int {
+        if constexpr (STAGED)
+            return s_ti[i];
+        else
+            return p.time_index[var_of(i)];
+    };
+    auto best_of = [&](int k) -> unsigned long long {
+        if constexpr (STAGED)
+            return s_best[k];
+        else if constexpr (MODE == 0)
+            return p.best[o0 + k];
+        else
+        {
+            int y = g_nbr[k];
+            unsigned long long wv = p.adj[(size_t)X * p.words + (y >> 6)];
+            return ((wv >> (y & 63)) & 1ull) ? kNone : 0ull;
+        }
+    };
+
+    const unsigned long long ncomb = p.binom[(size_t)d * (L + 1) + L];
+    const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
+    const unsigned long long cntr = min(p.chunk, ncomb - r0);
+    const unsigned long long q = (cntr + kThreads - 1) / kThreads;
+    unsigned long long lo = r0 + (unsigned long long)tid * q;
+    unsigned long long hi = min(r0 + cntr, lo + q);
+
+    unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
+    if (lo < hi)
+    {
+        int idx[L];
+        unrank_comb<L>(lo, d, p.binom, idx);
+        for (unsigned long long rank = lo; rank < hi; rank++)
+        {
+            float cl[SubsetFast<L>::NL], m1x[L];
+#pragma unroll
+            for (int a = 0; a < L; a++) m1x[a] = cval(d, idx[a]);
+#pragma unroll
+            for (int a = 1; a < L; a++)
+#pragma unroll
+                for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = cval(idx[b], idx[a]);
+            SubsetFast<L> fx;
+            fx.prepare(cl, m1x);
+            nsub++;
+            [[maybe_unused]] SubsetExact<L> cx;
+            if constexpr (VALIDATE)
+            {
+                float m2[L * L];
+#pragma unroll
+                for (int a = 0; a < L; a++)
+#pragma unroll
+                    for (int b = 0; b < L; b++)
+                        m2[a * L + b] = (a == b) ? 1.0f : (a < b ? cval(idx[a], idx[b]) : cval(idx[b], idx[a]));
+                cx.prepare(m2, m1x);
+            }
+            int tmaxS = 0;
+            [[maybe_unused]] float essS = 0.0f;
+            if constexpr (MODE == 1)
+            {
+                tmaxS = tix(idx[0]);
+#pragma unroll
+                for (int a = 1; a < L; a++) tmaxS = max(tmaxS, tix(idx[a]));
+            }
+            if constexpr (HET)
+            {
+                // filter-only estimate of the subset's part of mean_ess (summation order is free here)
+#pragma unroll
+                for (int a = 0; a < L; a++)
+                {
+                    essS += ess_term(eval(idx[a], d));
+#pragma unroll
+                    for (int b = 0; b < a; b++) essS += ess_term(eval(idx[a], idx[b]));
+                }
+            }
+            bool anyalive = false;
+            for (int k2 = 0; k2 < d; k2++)
+            {
+                const unsigned long long bk = best_of(k2);
+                const bool live = (MODE == 0) ? (bk >= rank) : (bk == kNone);
+                anyalive |= live;
+                if (!live) continue;
+                bool inS = false;
+#pragma unroll
+                for (int a = 0; a < L; a++) inS |= (idx[a] == k2);
+                if (inS) continue;
+                if constexpr (MODE == 1)
+                {
+                    if (tmaxS > max(tix(d), tix(k2))) continue;
+                }
+                ntests++;
+                int v = kUnsure;
+                float m1y[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) m1y[a] = cval(k2, idx[a]);
+                const float m0 = cval(d, k2);
+                [[maybe_unused]] float lthf = 0.0f;
+                if (!fx.ill)
+                {
+                    if constexpr (HET)
+                    {
+                        float s = essS + ess_term(eval(k2, d));
+#pragma unroll
+                        for (int a = 0; a < L; a++) s += ess_term(eval(idx[a], k2));
+                        const float me = s / (float)((L + 2) * (L + 1) / 2);
+                        lthf = p.th * __frsqrt_rn(me - (float)(L + 3));
+                        v = fx.verdict_z(m0, m1y, lthf);
+                    }
+                    else
+                    {
+                        v = fx.verdict_fixed(m0, m1y, p.t2);
+                    }
+                }
+                if constexpr (VALIDATE)
+                {
+                    if (v != kUnsure)
+                    {
+                        float lth = p.th;
+                        if constexpr (HET)
+                        {
+                            float s = 0.0f;
+                            s += ess_term(eval(k2, d));
+#pragma unroll
+                            for (int a = 0; a < L; a++)
+                            {
+                                s += ess_term(eval(idx[a], d));
+                                s += ess_term(eval(idx[a], k2));
+#pragma unroll
+                                for (int b = 0; b < a; b++) s += ess_term(eval(idx[a], idx[b]));
+                            }
+                            float me = s / (float)((L + 2) * (L + 1) / 2);
+                            lth = (float)((double)p.th / sqrt((double)me - (double)L - 3.0));
+                        }
+                        const bool ex = z_below<false>(cx.rho(m0, m1y), lth);
+                        if (ex != (v == kPass)) nbad++;
+                    }
+                }
+                if (v == kUnsure)
+                {
+                    const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
+                    if (qi < p.qcap)
+                    {
+                        RecheckEntry en;
+                        en.x = X;
+                        en.k2 = k2;
+                        en.rank = rank;
+                        p.queue[qi] = en;
+                    }
+                }
+                else if (v == kPass)
+                {
+                    if constexpr (MODE == 0)
+                    {
+                        unsigned long long old = atomicMin(&p.best[o0 + k2], rank);
+                        if constexpr (STAGED) atomicMin(&s_best[k2], rank);
+                        if (old == kNone) nrem++;
+                    }
+                    else
+                    {
+                        const int Y = var_of(k2);
+                        unsigned long long old =
+                            atomicAnd(&p.adj[(size_t)X * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
+                        atomicAnd(&p.adj[(size_t)Y * p.words + (X >> 6)], ~(1ull << (X & 63)));
+                        if constexpr (STAGED) s_best[k2] = 0ull;
+                        if ((old >> (Y & 63)) & 1ull) nrem++;
+                    }
+                }
+            }
+            if (!anyalive) break;
+            {
+                int i = L - 1;
+                while (i >= 0 && idx[i] == d - L + i) i--;
+                if (i < 0) break;
+                idx[i]++;
+                for (int j2 = i + 1; j2 < L; j2++) idx[j2] = idx[j2 - 1] + 1;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);
+        nsub += __shfl_xor(nsub, o);
+        nrem += __shfl_xor(nrem, o);
+        nbad += __shfl_xor(nbad, o);
+    }
+    if ((tid & 63) == 0)
+    {
+        atomicAdd(&s_cnt[0], ntests);
+        atomicAdd(&s_cnt[1], nsub);
+        atomicAdd(&s_cnt[2], nrem);
+        atomicAdd(&s_cnt[3], nbad);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        if (s_cnt[0]) atomicAdd(&p.cnt->tests, s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&p.cnt->subsets, s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&p.cnt->removed, s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&p.cnt->violations, s_cnt[3]);
+    }
+}
+
+// exact-path evaluation of the queued tests: one lane per entry, operands straight from HBM
+template <int L, int MODE, bool HET>
+__global__ void __launch_bounds__(256) recheck_kernel(SweepParams p, unsigned long long count)
+{
+    const unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= count) return;
+    const RecheckEntry en = p.queue[e];
+    const int X = en.x, k2 = en.k2;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int n = p.n;
+    int idx[L];
+    unrank_comb<L>(en.rank, d, p.binom, idx);
+    const int Y = p.nbr[o0 + k2];
+    int S[L];
+#pragma unroll
+    for (int a = 0; a < L; a++) S[a] = p.nbr[o0 + idx[a]];
+    float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
+#pragma unroll
+    for (int a = 0; a < L; a++)
+    {
+        m1x[a] = p.C[(size_t)X * n + S[a]];
+        m1y[a] = p.C[(size_t)Y * n + S[a]];
+    }
+    if constexpr (L >= 2)
+    {
+#pragma unroll
+        for (int a = 0; a < L; a++)
+#pragma unroll
+            for (int b = 0; b < L; b++)
+                m2[a * L + b] =
+                    (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
+    }
+    SubsetExact<L> cx;
+    cx.prepare(m2, m1x);
+    const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
+    float lth = p.th;
+    if constexpr (HET)
+    {
+        float s = 0.0f;
+        s += ess_term(p.Ness[(size_t)Y * n + X]);
+#pragma unroll
+        for (int a = 0; a < L; a++)
+        {
+            s += ess_term(p.Ness[(size_t)S[a] * n + X]);
+            s += ess_term(p.Ness[(size_t)S[a] * n + Y]);
+#pragma unroll
+            for (int b = 0; b < a; b++) s += ess_term(p.Ness[(size_t)S[a] * n + S[b]]);
+        }
+        float me = s / (float)((L + 2) * (L + 1) / 2);
+        lth = (float)((double)p.th / sqrt((double)me - (double)L - 3.0));
+    }
+    if (z_below<L == 1>(rho, lth))
+    {
+        if constexpr (MODE == 0)
+        {
+            unsigned long long old = atomicMin(&p.best[o0 + k2], en.rank);
+            if (old == kNone) atomicAdd(&p.cnt->removed, 1ull);
+        }
+        else
+        {
+            unsigned long long old = atomicAnd(&p.adj[(size_t)X * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
+            atomicAnd(&p.adj[(size_t)Y * p.words + (X >> 6)], ~(1ull << (X & 63)));
+            if ((old >> (Y & 63)) & 1ull) atomicAdd(&p.cnt->removed, 1ull);
+        }
+    }
+}
+
 // MODE 0 only: turn the per-slot winning ranks into sparse sepset records, recompute
 // the winner's Fisher z on the exact path (so pMax does not depend on which lane won)
 // and clear the edge in both directions.
@@ -679,6 +1058,89 @@ static hipError_t launch_sweep(int L, const SweepParams &p, int cls, long long n
     return hipErrorInvalidValue;
 }
 
+template <int L, int MODE, bool HET, bool VALIDATE>
+static hipError_t launch_fast_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    if (nitems <= 0) return hipSuccess;
+    const bool staged = (cls < kNumClasses - 1);
+    if (staged)
+    {
+        size_t lds = lds_layout(kClassCap[cls], HET).total;
+        auto kfn = sweep_fast_kernel<L, MODE, HET, true, VALIDATE>;
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    }
+    else
+    {
+        hipLaunchKernelGGL((sweep_fast_kernel<L, MODE, HET, false, VALIDATE>), dim3((unsigned)nitems), dim3(kThreads),
+                           16, st, p);
+    }
+    return hipGetLastError();
+}
+
+template <int MODE, bool HET>
+static hipError_t launch_fast(int L, bool validate, const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                                     \
+    case LL:                                                                              \
+        return validate ? launch_fast_L<LL, MODE, HET, true>(p, cls, nitems, st)          \
+                        : launch_fast_L<LL, MODE, HET, false>(p, cls, nitems, st);
+        CUSK_CASE(2)
+        CUSK_CASE(3)
+        CUSK_CASE(4)
+        CUSK_CASE(5)
+        CUSK_CASE(6)
+        CUSK_CASE(7)
+        CUSK_CASE(8)
+        CUSK_CASE(9)
+        CUSK_CASE(10)
+        CUSK_CASE(11)
+        CUSK_CASE(12)
+        CUSK_CASE(13)
+        CUSK_CASE(14)
+#undef CUSK_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+template <int MODE, bool HET>
+static hipError_t launch_recheck(int L, const SweepParams &p, unsigned long long count, hipStream_t st)
+{
+    if (count == 0) return hipSuccess;
+    dim3 grid((unsigned)((count + 255) / 256)), block(256);
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                                             \
+    case LL:                                                                                      \
+        hipLaunchKernelGGL((recheck_kernel<LL, MODE, HET>), grid, block, 0, st, p, count);        \
+        break;
+        CUSK_CASE(1)
+        CUSK_CASE(2)
+        CUSK_CASE(3)
+        CUSK_CASE(4)
+        CUSK_CASE(5)
+        CUSK_CASE(6)
+        CUSK_CASE(7)
+        CUSK_CASE(8)
+        CUSK_CASE(9)
+        CUSK_CASE(10)
+        CUSK_CASE(11)
+        CUSK_CASE(12)
+        CUSK_CASE(13)
+        CUSK_CASE(14)
+#undef CUSK_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
 static hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
 {
     dim3 grid((p.n + 3) / 4), block(256);
@@ -772,6 +1234,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     e->mode = a.mode;
     e->have_result = false;
     e->nrec = 0;
+    e->exact_fallbacks = 0;
     cusk_stats local;
     std::memset(&local, 0, sizeof(local));
     const bool het = (a.mode == 1 && a.Ness != nullptr);
@@ -879,7 +1342,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         int staged_classes = 0;
         while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
             staged_classes++;
-        const unsigned long long chunk = 2048;
+        const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
         hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, s, e->adj.as<unsigned long long>(),
                            e->off.as<int>(), e->nbr.as<int>(), n, words, l, e->binom.as<unsigned long long>(), chunk,
                            staged_classes, e->rowinfo.as<RowInfo>(), dcnt);
@@ -920,20 +1383,78 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         else
             sp.th = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
 
-        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
-        for (int c = 0; c < kNumClasses; c++)
+        const bool use_fast = (e->opt_fast != 0) && (l >= 2);
+        if (use_fast)
         {
-            if (nitems[c] <= 0) continue;
-            sp.items = e->items[c].as<int2>();
-            sp.cap = kClassCap[c];
-            hipError_t le;
-            if (a.mode == 0)
-                le = launch_sweep<0, false>(l, sp, c, nitems[c], s);
-            else if (het)
-                le = launch_sweep<1, true>(l, sp, c, nitems[c], s);
-            else
-                le = launch_sweep<1, false>(l, sp, c, nitems[c], s);
-            CUSK_HIP(e, le);
+            const double tq = std::tanh((double)sp.th);
+            sp.t2 = (float)(tq * tq);
+            CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
+            sp.queue = e->queue.as<RecheckEntry>();
+            sp.qcap = (unsigned long long)e->opt_queue_cap;
+        }
+        auto run_exact_sweeps = [&]() -> int {
+            for (int c = 0; c < kNumClasses; c++)
+            {
+                if (nitems[c] <= 0) continue;
+                sp.items = e->items[c].as<int2>();
+                sp.cap = kClassCap[c];
+                hipError_t le;
+                if (a.mode == 0)
+                    le = launch_sweep<0, false>(l, sp, c, nitems[c], s);
+                else if (het)
+                    le = launch_sweep<1, true>(l, sp, c, nitems[c], s);
+                else
+                    le = launch_sweep<1, false>(l, sp, c, nitems[c], s);
+                CUSK_HIP(e, le);
+            }
+            return CUSK_OK;
+        };
+        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
+        if (!use_fast)
+        {
+            int rc = run_exact_sweeps();
+            if (rc != CUSK_OK) return rc;
+        }
+        else
+        {
+            for (int c = 0; c < kNumClasses; c++)
+            {
+                if (nitems[c] <= 0) continue;
+                sp.items = e->items[c].as<int2>();
+                sp.cap = kClassCap[c];
+                hipError_t le;
+                if (a.mode == 0)
+                    le = launch_fast<0, false>(l, e->opt_validate != 0, sp, c, nitems[c], s);
+                else if (het)
+                    le = launch_fast<1, true>(l, e->opt_validate != 0, sp, c, nitems[c], s);
+                else
+                    le = launch_fast<1, false>(l, e->opt_validate != 0, sp, c, nitems[c], s);
+                CUSK_HIP(e, le);
+            }
+            // how many tests need the exact path?
+            CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+            const unsigned long long qn = e->hcnt->qcount;
+            local.rechecks[l] = (long long)qn;
+            if (qn > sp.qcap)
+            {
+                // queue overflow (pathologically ill-conditioned input): redo the level on the exact path.
+                // Everything the fast pass already recorded is a certified verdict, so it stays valid.
+                e->exact_fallbacks++;
+                int rc = run_exact_sweeps();
+                if (rc != CUSK_OK) return rc;
+            }
+            else if (qn > 0)
+            {
+                hipError_t le;
+                if (a.mode == 0)
+                    le = launch_recheck<0, false>(l, sp, qn, s);
+                else if (het)
+                    le = launch_recheck<1, true>(l, sp, qn, s);
+                else
+                    le = launch_recheck<1, false>(l, sp, qn, s);
+                CUSK_HIP(e, le);
+            }
         }
         CUSK_HIP(e, hipEventRecord(e->ev[3], s));
         if (a.mode == 0)
@@ -965,12 +1486,14 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         local.tests[l] = (long long)e->hcnt->tests;
         local.subsets[l] = (long long)e->hcnt->subsets;
         local.removed[l] = (long long)e->hcnt->removed;
+        local.violations += (long long)e->hcnt->violations;
         if (a.mode == 0) e->nrec = (long long)e->hcnt->nrec;
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
         local.kernel_ms[l] = ms;
         local.levels_run++;
     }
     local.level = l;
+    local.exact_fallbacks = e->exact_fallbacks;
     CUSK_HIP(e, hipEventRecord(e->ev[5], s));
     CUSK_HIP(e, hipEventSynchronize(e->ev[5]));
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[5]));
@@ -1096,7 +1619,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->off, &e->nbr, &e->best, &e->rowinfo, &e->binom, &e->counters,
                       &e->ti, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
-                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
+                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->queue})
         b->release();
     for (auto &b : e->items) b.release();
     if (e->hcnt) (void)hipHostFree(e->hcnt);
@@ -1104,6 +1627,23 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
         if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
+}
+
+extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long value)
+{
+    if (!e || !key) return CUSK_ERR_ARG;
+    const std::string k(key);
+    if (k == "fast")
+        e->opt_fast = (int)value;
+    else if (k == "validate")
+        e->opt_validate = (int)value;
+    else if (k == "queue_capacity" && value > 0)
+        e->opt_queue_cap = value;
+    else if (k == "chunk" && value >= 256)
+        e->opt_chunk = value;
+    else
+        return fail(e, CUSK_ERR_ARG, "unknown option " + k);
+    return CUSK_OK;
 }
 
 extern "C" const char *cusk_last_error(const cusk_engine *e) { return e ? e->err.c_str() : "no engine"; }

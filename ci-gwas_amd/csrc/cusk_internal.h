@@ -59,6 +59,8 @@ struct LevelCounters
     unsigned long long subsets;
     unsigned long long removed;
     unsigned long long nrec;
+    unsigned long long qcount;      // tests queued for the exact path (may exceed the capacity)
+    unsigned long long violations;  // validate mode: certain fast verdicts contradicted by the exact path
     int overflow;
     int pad1;
 };
@@ -83,6 +85,15 @@ struct cusk_engine
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
     long long nrec = 0;
     long long rec_cap = 0;
+    cusk::DevBuf queue;
+    // options (cusk_engine_set_option)
+    int opt_fast = 1;
+    int opt_validate = 0;
+    long long opt_queue_cap = 4ll << 20;
+    long long opt_chunk = 2048;
+    long long rechecks[CUSK_ML + 1] = {0};
+    long long violations = 0;
+    long long exact_fallbacks = 0;
     cusk::LevelCounters *hcnt = nullptr;  // pinned
     hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 

@@ -91,11 +91,15 @@ class Stats:
     kernel_ms: list
     level_ms: list
     total_ms: float
+    rechecks: list
+    violations: int
+    exact_fallbacks: int
 
     @staticmethod
     def of(s: CuskStats) -> "Stats":
         return Stats(s.level, s.levels_run, list(s.max_degree), list(s.edges), list(s.tests), list(s.subsets),
-                     list(s.removed), list(s.kernel_ms), list(s.level_ms), float(s.total_ms))
+                     list(s.removed), list(s.kernel_ms), list(s.level_ms), float(s.total_ms), list(s.rechecks),
+                     int(s.violations), int(s.exact_fallbacks))
 
 
 class DeviceArray:
@@ -153,6 +157,9 @@ class Engine:
     def _check(self, rc):
         if rc != 0:
             raise RuntimeError(f"libcusk_hip error {rc}: {lib().cusk_last_error(self.h).decode()}")
+
+    def set_option(self, key: str, value: int) -> None:
+        self._check(lib().cusk_engine_set_option(self.h, key.encode(), int(value)))
 
     @property
     def stream(self) -> int:

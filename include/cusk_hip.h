@@ -99,6 +99,9 @@ typedef struct cusk_stats {
     float kernel_ms[CUSK_ML + 1];     /* HIP-event time of the level's sweep kernels */
     float level_ms[CUSK_ML + 1];      /* HIP-event time of the whole level (compaction + sweep + finalise) */
     float total_ms;                   /* whole run, events on the engine stream */
+    long long rechecks[CUSK_ML + 1];  /* tests the fast filter could not certify (re-evaluated on the exact path) */
+    long long violations;             /* validate mode only: certified verdicts contradicted by the exact path */
+    long long exact_fallbacks;        /* levels redone entirely on the exact path (recheck queue overflow) */
 } cusk_stats;
 
 /* device = HIP device ordinal; stream = a hipStream_t to run on, or NULL for a
@@ -106,6 +109,11 @@ typedef struct cusk_stats {
 int cusk_engine_create(cusk_engine **out, int device, void *stream);
 void cusk_engine_destroy(cusk_engine *e);
 const char *cusk_last_error(const cusk_engine *e);
+/* options: "fast" (default 1: register-Cholesky filter + exact recheck for levels >= 2; 0: exact
+ * arithmetic for every test), "validate" (default 0; 1: also run the exact path on every certified
+ * verdict and count contradictions in cusk_stats.violations), "queue_capacity" (recheck queue
+ * entries, default 4Mi), "chunk" (combination ranks per work item, default 2048). */
+int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
 
 /* Level sweep on a matrix already resident in HBM (C_dev: n*n fp32 row-major).

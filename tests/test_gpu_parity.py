@@ -180,6 +180,64 @@ def test_edge_cases(cg, eng, oracle):
     assert np.array_equal(G, ref.G) and level == ref.level
 
 
+@pytest.mark.parametrize("mode", ["skeleton", "hetcor", "het"])
+def test_fast_filter_never_contradicts_exact_path(cg, oracle, synth, mode):
+    """validate mode evaluates BOTH paths for every certified verdict: zero contradictions,
+    and the exact-only engine (fast = 0) gives the same answer as the filtered one."""
+    e = cg.Engine(0)
+    e.set_option("validate", 1)
+    rng = np.random.default_rng(3)
+    mats = [synth.synth_corr_block(500, 8, N=4096, block_index=31), synth.random_corr(40, seed=21, k=300, strength=1.2)]
+    for Cm, N, alpha, ml in [(mats[0], 4096, 1e-4, 5), (mats[1], 300, 0.1, 7)]:
+        n = Cm.shape[0]
+        Cd = cg.DeviceArray(Cm)
+        if mode == "skeleton":
+            Th = cg.threshold_array(N, alpha)
+            st = e.run_skeleton(Cd.ptr, n, Th, ml)
+            ref = oracle.skeleton(Cm, Th, ml)
+            G = e.adjacency()
+            e.set_option("fast", 0)
+            st0 = e.run_skeleton(Cd.ptr, n, Th, ml)
+            e.set_option("fast", 1)
+            assert np.array_equal(e.adjacency(), G)
+        else:
+            th = cg.hetcor_threshold(alpha)
+            Nm = np.full((n, n), N, np.float32)
+            if mode == "het":
+                Nm = (Nm * rng.uniform(0.6, 1.0, (n, n))).astype(np.float32)
+                Nm = np.maximum(Nm, Nm.T)
+            Nd = cg.DeviceArray(Nm)
+            st = e.run_hetcor(Cd.ptr, n, th, ml, N_dev=Nd.ptr if mode == "het" else None, ess_uniform=float(N))
+            ref = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), Nm, th, ml, np.zeros(n, np.int32))
+            G = e.adjacency()
+            Nd.free()
+        assert st.violations == 0 and st.exact_fallbacks == 0
+        assert np.array_equal(G, ref.G) and st.level == ref.level
+        assert sum(st.rechecks) < 0.05 * max(1, sum(st.tests[2:])) + 1000
+        Cd.free()
+    e.close()
+
+
+def test_recheck_queue_overflow_falls_back_to_exact(cg, oracle, synth):
+    e = cg.Engine(0)
+    e.set_option("queue_capacity", 1)
+    rng = np.random.default_rng(8)
+    X = rng.standard_normal((30, 60))
+    X[1] = X[0] + 0.05 * rng.standard_normal(60)  # nearly collinear -> ill-conditioned sets -> many rechecks
+    Cm = np.corrcoef(X).astype(np.float32)
+    Cm = np.ascontiguousarray(np.triu(Cm, 1) + np.triu(Cm, 1).T + np.eye(30, dtype=np.float32))
+    Th = cg.threshold_array(60, 0.3)
+    Cd = cg.DeviceArray(Cm)
+    st = e.run_skeleton(Cd.ptr, 30, Th, 5)
+    ref = oracle.skeleton(Cm, Th, 5)
+    assert st.exact_fallbacks > 0
+    assert np.array_equal(e.adjacency(), ref.G) and st.level == ref.level
+    x, y, lv, z, S = e.sepsets()
+    assert np.array_equal(_dense_sepsets(30, x, y, S), ref.sepset)
+    Cd.free()
+    e.close()
+
+
 # ---------------------------------------------------------------- correlation build
 def test_corr_kat_bmt(cg, kat):
     for key, mm, mp, pp in [("bmt", "exp_mxm", "exp_mxp", "exp_pxp"), ("bmt2", "exp_mxm_npn", "exp_mxp_pearson", "exp_pxp")]:
