@@ -63,7 +63,7 @@ __global__ void init_bits_kernel(unsigned long long *adj, const int *Ginit, int 
 template <bool ESS>
 __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C, const float *__restrict__ N,
                                                       unsigned long long *adj, int n, int words, float th,
-                                                      int tiles)
+                                                      int tiles, int *asym_flag)
 {
     __shared__ unsigned long long s_col[64];
     // linear tile id -> (bi <= bj)
@@ -95,6 +95,9 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
         if (i < n && j < n && i < j)
         {
             float c = C[(size_t)i * n + j];
+            // is the matrix bitwise symmetric?  (lets level 1 read only the upper triangle)
+            float ct = C[(size_t)j * n + i];
+            if (__float_as_uint(c) != __float_as_uint(ct) && !((c != c) && (ct != ct))) *asym_flag = 1;
             float lth = th;
             if constexpr (ESS) lth = (float)((double)th / sqrt((double)N[(size_t)i * n + j] - 3.0));
             rm = z_below<false>(c, lth);
@@ -174,7 +177,7 @@ struct RowInfo
 // one wave per row: write ascending neighbour indices, count the row's work items
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off,
                                 int *nbr, int n, int words, int L, const unsigned long long *__restrict__ binom,
-                                unsigned long long chunk, int staged_classes, RowInfo *rowinfo,
+                                unsigned long long chunk, int staged_classes, int pair_mode, RowInfo *rowinfo,
                                 LevelCounters *cnt)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -212,7 +215,8 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
         ri.pad = 0;
         if (d > L)
         {
-            unsigned long long nc = binom[(size_t)d * (L + 1) + L];
+            // work units of the row: conditioning sets, or unordered neighbour pairs for the level-1 pair kernel
+            unsigned long long nc = pair_mode ? (unsigned long long)d * (d - 1) / 2 : binom[(size_t)d * (L + 1) + L];
             if (nc >= (1ull << 62))
             {
                 cnt->overflow = 1;
@@ -551,6 +555,155 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
     }
 }
 
+
+// Level 1 on a symmetric matrix (fixed or uniform-ESS threshold).  A level-1 test
+// (X ; Y | S) needs C[X,Y], C[X,S] and C[Y,S]; the first two live in row X and are staged once,
+// the third is used by exactly two tests, (X;Y|S) and (X;S|Y), so staging a (d+1)^2 sub-matrix
+// buys no reuse.  Lane <-> unordered neighbour pair {a<b}: ONE 4-byte gather of the upper-triangle
+// element C[min,max] feeds both tests, pairs whose two tests are already decided are skipped
+// without touching memory, and with ~20 VGPRs the kernel runs at full occupancy to hide the
+// gather latency.  Arithmetic is the exact level-1 formula (cuPC-S.cu:561-566), so no recheck.
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[3];
+    const int2 item = p.items[blockIdx.x];
+    const int X = item.x;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(smem);
+    int *s_nbr = reinterpret_cast<int *>(smem + sizeof(unsigned long long) * d);
+    float *s_m1x = reinterpret_cast<float *>(s_nbr + d);
+    int *s_ti = reinterpret_cast<int *>(s_m1x + d);
+    const int *g_nbr = p.nbr + o0;
+    if (tid < 3) s_cnt[tid] = 0ull;
+    for (int k = tid; k < d; k += kThreads)
+    {
+        const int y = g_nbr[k];
+        s_nbr[k] = y;
+        s_m1x[k] = p.C[(size_t)X * n + y];
+        if constexpr (MODE == 0)
+            s_best[k] = p.best[o0 + k];
+        else
+        {
+            unsigned long long wv = p.adj[(size_t)X * p.words + (y >> 6)];
+            s_best[k] = ((wv >> (y & 63)) & 1ull) ? kNone : 0ull;
+            s_ti[k] = p.time_index[y];
+        }
+    }
+    __syncthreads();
+    [[maybe_unused]] int tiX = 0;
+    if constexpr (MODE == 1) tiX = p.time_index[X];
+
+    const unsigned long long npairs = (unsigned long long)d * (d - 1) / 2;
+    const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
+    const unsigned long long cntr = min(p.chunk, npairs - r0);
+    const unsigned long long q = (cntr + kThreads - 1) / kThreads;
+    unsigned long long lo = r0 + (unsigned long long)tid * q;
+    const unsigned long long hi = min(r0 + cntr, lo + q);
+    unsigned long long ntests = 0, nrem = 0;
+    if (lo < hi)
+    {
+        // unrank the pair: rows of the strict upper triangle have d-1-a entries
+        int a = 0;
+        {
+            unsigned long long rem = lo;
+            // closed form start then fix up (exact in integers)
+            double dd = (double)d - 0.5;
+            int guess = (int)(dd - sqrt(dd * dd - 2.0 * (double)rem));
+            if (guess < 0) guess = 0;
+            if (guess > d - 2) guess = d - 2;
+            a = guess;
+            auto start_of = [&](int aa) -> unsigned long long {
+                return (unsigned long long)aa * d - (unsigned long long)aa * (aa + 1) / 2;
+            };
+            while (a > 0 && start_of(a) > rem) a--;
+            while (a < d - 2 && start_of(a + 1) <= rem) a++;
+            lo = rem - start_of(a);  // reuse lo as offset inside row a
+        }
+        int b = a + 1 + (int)lo;
+        const unsigned long long count = hi - (r0 + (unsigned long long)tid * q);
+        auto apply = [&](int ky, int ks) {
+            // edge X - nbr[ky] is separated by S = nbr[ks]
+            if constexpr (MODE == 0)
+            {
+                unsigned long long old = atomicMin(&p.best[o0 + ky], (unsigned long long)ks);
+                atomicMin(&s_best[ky], (unsigned long long)ks);
+                if (old == kNone) nrem++;
+            }
+            else
+            {
+                const int Y = s_nbr[ky];
+                unsigned long long old = atomicAnd(&p.adj[(size_t)X * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
+                atomicAnd(&p.adj[(size_t)Y * p.words + (X >> 6)], ~(1ull << (X & 63)));
+                s_best[ky] = 0ull;
+                if ((old >> (Y & 63)) & 1ull) nrem++;
+            }
+        };
+        for (unsigned long long it = 0; it < count; it++)
+        {
+            bool needA, needB;  // A: Y = a, S = b ; B: Y = b, S = a
+            if constexpr (MODE == 0)
+            {
+                needA = s_best[a] >= (unsigned long long)b;
+                needB = s_best[b] >= (unsigned long long)a;
+            }
+            else
+            {
+                needA = (s_best[a] == kNone) && !(s_ti[b] > max(tiX, s_ti[a]));
+                needB = (s_best[b] == kNone) && !(s_ti[a] > max(tiX, s_ti[b]));
+            }
+            if (needA || needB)
+            {
+                const int ya = s_nbr[a], yb = s_nbr[b];  // ascending lists: ya < yb
+                const float c = p.C[(size_t)ya * n + yb];
+                const float ra = s_m1x[a], rb = s_m1x[b];
+                const float hc = 1.0f - (c * c);
+                if (needA)
+                {
+                    const float H00 = 1.0f - (rb * rb);
+                    const float H01 = ra - (rb * c);
+                    const float rho = H01 / (sqrtf(fabsf(H00)) * sqrtf(fabsf(hc)));
+                    ntests++;
+                    if (z_below<true>(rho, p.th)) apply(a, b);
+                }
+                if (needB)
+                {
+                    const float H00 = 1.0f - (ra * ra);
+                    const float H01 = rb - (ra * c);
+                    const float rho = H01 / (sqrtf(fabsf(H00)) * sqrtf(fabsf(hc)));
+                    ntests++;
+                    if (z_below<true>(rho, p.th)) apply(b, a);
+                }
+            }
+            b++;
+            if (b == d)
+            {
+                a++;
+                b = a + 1;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);
+        nrem += __shfl_xor(nrem, o);
+    }
+    if ((tid & 63) == 0)
+    {
+        atomicAdd(&s_cnt[0], ntests);
+        atomicAdd(&s_cnt[2], nrem);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        if (s_cnt[0]) atomicAdd(&p.cnt->tests, s_cnt[0]);
+        if (s_cnt[2]) atomicAdd(&p.cnt->removed, s_cnt[2]);
+    }
+}
 
 // unrank a 0-based lexicographic combination rank into ascending positions idx[0..L) out of d
 template <int L>
@@ -1255,6 +1408,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             CUSK_HIP(e, hipMemsetAsync(e->ti.p, 0, sizeof(int) * (size_t)n, s));
     }
 
+    CUSK_HIP(e, e->symflag.ensure(sizeof(int)));
+    CUSK_HIP(e, hipMemsetAsync(e->symflag.p, 0, sizeof(int), s));
     CUSK_HIP(e, hipEventRecord(e->ev[0], s));
     // ---- level 0 ----
     {
@@ -1264,13 +1419,13 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         const long long ntile = (long long)tiles * (tiles + 1) / 2;
         if (het)
             hipLaunchKernelGGL(level0_kernel<true>, dim3((unsigned)ntile), dim3(256), 0, s, a.C, a.Ness,
-                               e->adj.as<unsigned long long>(), n, words, a.Th[0], tiles);
+                               e->adj.as<unsigned long long>(), n, words, a.Th[0], tiles, e->symflag.as<int>());
         else
         {
             float th0 = a.Th[0];
             if (a.mode == 1) th0 = (float)((double)a.Th[0] / std::sqrt((double)a.ess_uniform - 3.0));
             hipLaunchKernelGGL(level0_kernel<false>, dim3((unsigned)ntile), dim3(256), 0, s, a.C, nullptr,
-                               e->adj.as<unsigned long long>(), n, words, th0, tiles);
+                               e->adj.as<unsigned long long>(), n, words, th0, tiles, e->symflag.as<int>());
         }
         CUSK_HIP(e, hipGetLastError());
         if (a.mode == 0)
@@ -1285,6 +1440,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     float ms = 0.0f;
     int l = 0;
     bool finished = false;
+    bool symmetric = false;
     for (l = 0; l <= kML && !finished && l <= a.maxlevel; l++)
     {
         if (l == 0)
@@ -1300,7 +1456,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                            e->deg.as<int>(), n, words, dcnt);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, e->deg.as<int>(), e->off.as<int>(), n, dcnt);
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+        if (l == 1) CUSK_HIP(e, hipMemcpyAsync(e->hflag, e->symflag.p, sizeof(int), hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipStreamSynchronize(s));
+        if (l == 1) symmetric = (*e->hflag == 0);
         const int maxdeg = e->hcnt->maxdeg;
         const long long total = e->hcnt->total_edges;
         local.max_degree[l] = maxdeg;
@@ -1343,9 +1501,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
             staged_classes++;
         const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+        // level 1 on a symmetric matrix with a single threshold: pair kernel (one gather feeds two tests)
+        const size_t pair_lds = (size_t)maxdeg * 20 + 16;
+        const bool use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pair_lds <= 64 * 1024;
         hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, s, e->adj.as<unsigned long long>(),
                            e->off.as<int>(), e->nbr.as<int>(), n, words, l, e->binom.as<unsigned long long>(), chunk,
-                           staged_classes, e->rowinfo.as<RowInfo>(), dcnt);
+                           staged_classes, use_pair ? 1 : 0, e->rowinfo.as<RowInfo>(), dcnt);
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipStreamSynchronize(s));
         if (e->hcnt->overflow)
@@ -1410,7 +1571,20 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             return CUSK_OK;
         };
         CUSK_HIP(e, hipEventRecord(e->ev[2], s));
-        if (!use_fast)
+        if (use_pair)
+        {
+            for (int c = 0; c < kNumClasses; c++)
+            {
+                if (nitems[c] <= 0) continue;
+                sp.items = e->items[c].as<int2>();
+                if (a.mode == 0)
+                    hipLaunchKernelGGL(level1_pair_kernel<0>, dim3((unsigned)nitems[c]), dim3(kThreads), pair_lds, s, sp);
+                else
+                    hipLaunchKernelGGL(level1_pair_kernel<1>, dim3((unsigned)nitems[c]), dim3(kThreads), pair_lds, s, sp);
+                CUSK_HIP(e, hipGetLastError());
+            }
+        }
+        else if (!use_fast)
         {
             int rc = run_exact_sweeps();
             if (rc != CUSK_OK) return rc;
@@ -1602,6 +1776,11 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         delete e;
         return CUSK_ERR_HIP;
     }
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) != hipSuccess)
+    {
+        delete e;
+        return CUSK_ERR_HIP;
+    }
     for (auto &ev : e->ev)
         if (hipEventCreate(&ev) != hipSuccess)
         {
@@ -1619,10 +1798,11 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->off, &e->nbr, &e->best, &e->rowinfo, &e->binom, &e->counters,
                       &e->ti, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
-                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->queue})
+                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->queue, &e->symflag})
         b->release();
     for (auto &b : e->items) b.release();
     if (e->hcnt) (void)hipHostFree(e->hcnt);
+    if (e->hflag) (void)hipHostFree(e->hflag);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1637,6 +1817,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_fast = (int)value;
     else if (k == "validate")
         e->opt_validate = (int)value;
+    else if (k == "pair")
+        e->opt_pair = (int)value;
     else if (k == "queue_capacity" && value > 0)
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)

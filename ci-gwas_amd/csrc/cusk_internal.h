@@ -62,7 +62,7 @@ struct LevelCounters
     unsigned long long qcount;      // tests queued for the exact path (may exceed the capacity)
     unsigned long long violations;  // validate mode: certain fast verdicts contradicted by the exact path
     int overflow;
-    int pad1;
+    int asymmetric;  // set by level 0 when C[i][j] != C[j][i] somewhere
 };
 
 }  // namespace cusk
@@ -85,7 +85,9 @@ struct cusk_engine
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
     long long nrec = 0;
     long long rec_cap = 0;
-    cusk::DevBuf queue;
+    cusk::DevBuf queue, symflag;
+    int *hflag = nullptr;  // pinned
+    int opt_pair = 1;
     // options (cusk_engine_set_option)
     int opt_fast = 1;
     int opt_validate = 0;

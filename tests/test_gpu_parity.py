@@ -218,6 +218,24 @@ def test_fast_filter_never_contradicts_exact_path(cg, oracle, synth, mode):
     e.close()
 
 
+def test_asymmetric_matrix_and_generic_level1(cg, eng, oracle, synth):
+    """the reference reads C[X,Y], C[X,S], C[Y,S], C[S_a,S_b] (a<b) at exactly those positions;
+    an asymmetric matrix must take the generic level-1 kernel and still match the oracle"""
+    Cm = synth.synth_corr_block(300, 6, N=4096, block_index=5).copy()
+    rng = np.random.default_rng(1)
+    il = np.tril_indices(Cm.shape[0], -1)
+    Cm[il] = (Cm[il] + rng.normal(0, 2e-3, len(il[0]))).astype(np.float32)
+    Th = cg.threshold_array(4096, 1e-4)
+    _check_skeleton(cg, eng, oracle, Cm, Th, 4)
+    # symmetric matrix through the generic level-1 kernel (pair kernel disabled)
+    Cs = synth.synth_corr_block(300, 6, N=4096, block_index=6)
+    eng.set_option("pair", 0)
+    try:
+        _check_skeleton(cg, eng, oracle, Cs, Th, 3)
+    finally:
+        eng.set_option("pair", 1)
+
+
 def test_recheck_queue_overflow_falls_back_to_exact(cg, oracle, synth):
     e = cg.Engine(0)
     e.set_option("queue_capacity", 1)
