@@ -66,6 +66,7 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
                                                       int tiles, int *asym_flag)
 {
     __shared__ unsigned long long s_col[64];
+    __shared__ float s_t[64][65];  // mirrored tile C[bj rows][bi cols], for the symmetry check
     // linear tile id -> (bi <= bj)
     int t = blockIdx.x;
     int bi = 0;
@@ -84,6 +85,12 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
     const int bj = t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 64) s_col[threadIdx.x] = 0ull;
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int r = wave * 16 + rr;
+        const int jr = bj * 64 + r, ic = bi * 64 + lane;
+        s_t[r][lane] = (jr < n && ic < n) ? C[(size_t)jr * n + ic] : 0.0f;
+    }
     __syncthreads();
     const int j = bj * 64 + lane;
     unsigned long long colbits = 0ull;
@@ -96,7 +103,7 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
         {
             float c = C[(size_t)i * n + j];
             // is the matrix bitwise symmetric?  (lets level 1 read only the upper triangle)
-            float ct = C[(size_t)j * n + i];
+            float ct = s_t[lane][r];
             if (__float_as_uint(c) != __float_as_uint(ct) && !((c != c) && (ct != ct))) *asym_flag = 1;
             float lth = th;
             if constexpr (ESS) lth = (float)((double)th / sqrt((double)N[(size_t)i * n + j] - 3.0));
@@ -132,7 +139,7 @@ __global__ void degree_kernel(const unsigned long long *__restrict__ adj, int *d
     if (lane == 0)
     {
         deg[row] = d;
-        atomicMax(&cnt->maxdeg, d);
+        if (d > *reinterpret_cast<volatile int *>(&cnt->maxdeg)) atomicMax(&cnt->maxdeg, d);
     }
 }
 
@@ -229,10 +236,60 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
                 if (cls >= staged_classes) cls = kNumClasses - 1;
                 ri.cls = cls;
                 ri.nchunks = (int)k;
-                ri.base = (int)atomicAdd((unsigned long long *)&cnt->class_items[cls], k);
             }
         }
         rowinfo[row] = ri;
+    }
+}
+
+// single workgroup: per-class exclusive scan of the rows' item counts -> RowInfo.base, class totals
+__global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
+{
+    __shared__ long long s_part[kNumClasses][1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    long long sum[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) sum[c] = 0;
+    for (int i = lo; i < hi; i++)
+    {
+        const RowInfo ri = rowinfo[i];
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++)
+            if (ri.cls == c) sum[c] += ri.nchunks;
+    }
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] = sum[c];
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1)
+    {
+        long long v[kNumClasses];
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) v[c] = (threadIdx.x >= step) ? s_part[c][threadIdx.x - step] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] += v[c];
+        __syncthreads();
+    }
+    long long run[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) run[c] = (threadIdx.x == 0) ? 0 : s_part[c][threadIdx.x - 1];
+    for (int i = lo; i < hi; i++)
+    {
+        RowInfo ri = rowinfo[i];
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++)
+            if (ri.cls == c)
+            {
+                ri.base = (int)run[c];
+                run[c] += ri.nchunks;
+            }
+        rowinfo[i] = ri;
+    }
+    if (threadIdx.x == 1023)
+    {
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) cnt->class_items[c] = s_part[c][1023];
     }
 }
 
@@ -280,6 +337,7 @@ struct SweepParams
     unsigned long long chunk;
     int cap;  // class capacity (LDS carve), ignored when !STAGED
     LevelCounters *cnt;
+    unsigned long long *slots;  // kCounterSlots x 4 spread counters: tests, subsets, removed, violations
     // fast path (ci_fast.h)
     float t2;                  // tanh(th)^2 for fixed-threshold modes
     RecheckEntry *queue;       // tests that need the exact path
@@ -549,9 +607,10 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
     __syncthreads();
     if (tid == 0)
     {
-        if (s_cnt[0]) atomicAdd(&p.cnt->tests, s_cnt[0]);
-        if (s_cnt[1]) atomicAdd(&p.cnt->subsets, s_cnt[1]);
-        if (s_cnt[2]) atomicAdd(&p.cnt->removed, s_cnt[2]);
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&sl[1], s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
     }
 }
 
@@ -700,8 +759,9 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
     __syncthreads();
     if (tid == 0)
     {
-        if (s_cnt[0]) atomicAdd(&p.cnt->tests, s_cnt[0]);
-        if (s_cnt[2]) atomicAdd(&p.cnt->removed, s_cnt[2]);
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
     }
 }
 
@@ -996,10 +1056,11 @@ __global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
     __syncthreads();
     if (tid == 0)
     {
-        if (s_cnt[0]) atomicAdd(&p.cnt->tests, s_cnt[0]);
-        if (s_cnt[1]) atomicAdd(&p.cnt->subsets, s_cnt[1]);
-        if (s_cnt[2]) atomicAdd(&p.cnt->removed, s_cnt[2]);
-        if (s_cnt[3]) atomicAdd(&p.cnt->violations, s_cnt[3]);
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[1]) atomicAdd(&sl[1], s_cnt[1]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&sl[3], s_cnt[3]);
     }
 }
 
@@ -1060,13 +1121,13 @@ __global__ void __launch_bounds__(256) recheck_kernel(SweepParams p, unsigned lo
         if constexpr (MODE == 0)
         {
             unsigned long long old = atomicMin(&p.best[o0 + k2], en.rank);
-            if (old == kNone) atomicAdd(&p.cnt->removed, 1ull);
+            if (old == kNone) atomicAdd(&p.slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], 1ull);
         }
         else
         {
             unsigned long long old = atomicAnd(&p.adj[(size_t)X * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
             atomicAnd(&p.adj[(size_t)Y * p.words + (X >> 6)], ~(1ull << (X & 63)));
-            if ((old >> (Y & 63)) & 1ull) atomicAdd(&p.cnt->removed, 1ull);
+            if ((old >> (Y & 63)) & 1ull) atomicAdd(&p.slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], 1ull);
         }
     }
 }
@@ -1098,10 +1159,18 @@ __global__ void finalize_kernel(FinalizeParams p)
     const int o0 = p.off[row];
     const int d = p.off[row + 1] - o0;
     const int n = p.n;
-    for (int k = lane; k < d; k += 64)
+    for (int k0 = 0; k0 < d; k0 += 64)
     {
-        const unsigned long long r = p.best[o0 + k];
+        const int k = k0 + lane;
+        const unsigned long long r = (k < d) ? p.best[o0 + k] : kNone;
+        // one atomic per wave: the leader reserves slots for every lane that has a record
+        const unsigned long long has = __ballot(r != kNone);
+        if (has == 0ull) continue;
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(&p.cnt->nrec, (unsigned long long)__popcll(has));
+        base = __shfl(base, 0);
         if (r == kNone) continue;
+        const unsigned long long slot = base + (unsigned long long)__popcll(has & ((1ull << lane) - 1ull));
         int idx[L];
         {
             unsigned long long rem = r;
@@ -1145,7 +1214,6 @@ __global__ void finalize_kernel(FinalizeParams p)
         const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
         float z;
         (void)z_below<L == 1>(rho, 0.0f, &z);
-        const unsigned long long slot = atomicAdd(&p.cnt->nrec, 1ull);
         p.rec_x[slot] = X;
         p.rec_y[slot] = Y;
         p.rec_l[slot] = L;
@@ -1399,6 +1467,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     CUSK_HIP(e, e->rowinfo.ensure(sizeof(RowInfo) * (size_t)n));
     CUSK_HIP(e, e->counters.ensure(sizeof(LevelCounters)));
     LevelCounters *dcnt = e->counters.as<LevelCounters>();
+    CUSK_HIP(e, e->slots.ensure(sizeof(unsigned long long) * kCounterSlots * 4));
     if (a.mode == 1)
     {
         CUSK_HIP(e, e->ti.ensure(sizeof(int) * (size_t)n));
@@ -1452,6 +1521,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         }
         CUSK_HIP(e, hipEventRecord(e->ev[1], s));
         CUSK_HIP(e, hipMemsetAsync(dcnt, 0, sizeof(LevelCounters), s));
+        CUSK_HIP(e, hipMemsetAsync(e->slots.p, 0, sizeof(unsigned long long) * kCounterSlots * 4, s));
         hipLaunchKernelGGL(degree_kernel, dim3((n + 3) / 4), dim3(256), 0, s, e->adj.as<unsigned long long>(),
                            e->deg.as<int>(), n, words, dcnt);
         hipLaunchKernelGGL(scan_kernel, dim3(1), dim3(1024), 0, s, e->deg.as<int>(), e->off.as<int>(), n, dcnt);
@@ -1507,6 +1577,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, s, e->adj.as<unsigned long long>(),
                            e->off.as<int>(), e->nbr.as<int>(), n, words, l, e->binom.as<unsigned long long>(), chunk,
                            staged_classes, use_pair ? 1 : 0, e->rowinfo.as<RowInfo>(), dcnt);
+        hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, s, e->rowinfo.as<RowInfo>(), n, dcnt);
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipStreamSynchronize(s));
         if (e->hcnt->overflow)
@@ -1537,6 +1608,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         sp.time_index = e->ti.as<int>();
         sp.chunk = chunk;
         sp.cnt = dcnt;
+        sp.slots = e->slots.as<unsigned long long>();
         if (a.mode == 0)
             sp.th = a.Th[l];
         else if (het)
@@ -1653,14 +1725,19 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             CUSK_HIP(e, launch_finalize(l, fp, s));
         }
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+        CUSK_HIP(e, hipMemcpyAsync(e->hslots, e->slots.p, sizeof(unsigned long long) * kCounterSlots * 4,
+                                   hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipEventRecord(e->ev[4], s));
         CUSK_HIP(e, hipStreamSynchronize(s));
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[1], e->ev[4]));
         local.level_ms[l] = ms;
-        local.tests[l] = (long long)e->hcnt->tests;
-        local.subsets[l] = (long long)e->hcnt->subsets;
-        local.removed[l] = (long long)e->hcnt->removed;
-        local.violations += (long long)e->hcnt->violations;
+        for (int k = 0; k < kCounterSlots; k++)
+        {
+            local.tests[l] += (long long)e->hslots[k * 4 + 0];
+            local.subsets[l] += (long long)e->hslots[k * 4 + 1];
+            local.removed[l] += (long long)e->hslots[k * 4 + 2];
+            local.violations += (long long)e->hslots[k * 4 + 3];
+        }
         if (a.mode == 0) e->nrec = (long long)e->hcnt->nrec;
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
         local.kernel_ms[l] = ms;
@@ -1776,6 +1853,11 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         delete e;
         return CUSK_ERR_HIP;
     }
+    if (hipHostMalloc(reinterpret_cast<void **>(&e->hslots), sizeof(unsigned long long) * kCounterSlots * 4) != hipSuccess)
+    {
+        delete e;
+        return CUSK_ERR_HIP;
+    }
     if (hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) != hipSuccess)
     {
         delete e;
@@ -1798,11 +1880,12 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->off, &e->nbr, &e->best, &e->rowinfo, &e->binom, &e->counters,
                       &e->ti, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
-                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->queue, &e->symflag})
+                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->queue, &e->symflag, &e->slots})
         b->release();
     for (auto &b : e->items) b.release();
     if (e->hcnt) (void)hipHostFree(e->hcnt);
     if (e->hflag) (void)hipHostFree(e->hflag);
+    if (e->hslots) (void)hipHostFree(e->hslots);
     for (auto &ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);

@@ -18,6 +18,7 @@ constexpr unsigned long long kNone = ~0ull;
 constexpr int kNumClasses = 5;
 constexpr int kClassCap[kNumClasses] = {31, 63, 127, 191, 1 << 30};
 constexpr int kThreads = 256;
+constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many lines' worth of slots
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct DevBuf
@@ -85,7 +86,8 @@ struct cusk_engine
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
     long long nrec = 0;
     long long rec_cap = 0;
-    cusk::DevBuf queue, symflag;
+    cusk::DevBuf queue, symflag, slots;
+    unsigned long long *hslots = nullptr;  // pinned
     int *hflag = nullptr;  // pinned
     int opt_pair = 1;
     // options (cusk_engine_set_option)
