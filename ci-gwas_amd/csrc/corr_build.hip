@@ -307,7 +307,7 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     CUSK_HIP(e, e->mean_dev.ensure(sizeof(float) * m));
     CUSK_HIP(e, e->std_dev.ensure(sizeof(float) * m));
     CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
-    CUSK_HIP(e, hipEventRecord(e->ev[0], s));
+    CUSK_HIP(e, hipEventRecord(e->ev_corr[0], s));
     CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
     if (p) CUSK_HIP(e, hipMemcpyAsync(e->phen_dev.p, phen, sizeof(float) * p * N, hipMemcpyHostToDevice, s));
     CUSK_HIP(e, hipMemcpyAsync(e->mean_dev.p, mean, sizeof(float) * m, hipMemcpyHostToDevice, s));
@@ -318,12 +318,12 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         CUSK_HIP(e, e->mxp_dev.ensure(sizeof(float) * m * p));
         mxp_d = e->mxp_dev.as<float>();
     }
-    CUSK_HIP(e, hipEventRecord(e->ev[1], s));
+    CUSK_HIP(e, hipEventRecord(e->ev_corr[1], s));
     if (C_dev)
     {
         hipLaunchKernelGGL(bed_to_bitplanes_kernel, dim3((unsigned)((m * w64 + 255) / 256)), dim3(256), 0, s,
                            e->bed_dev.as<unsigned char>(), e->planes.as<unsigned long long>(), m, N, clb, w64);
-        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
+        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kTile - 1) / kTile);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
         hipLaunchKernelGGL(mxm_popcount_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->planes.as<unsigned long long>(),
@@ -332,9 +332,9 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     }
     else
     {
-        CUSK_HIP(e, hipEventRecord(e->ev[2], s));
+        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
     }
-    CUSK_HIP(e, hipEventRecord(e->ev[3], s));
+    CUSK_HIP(e, hipEventRecord(e->ev_corr[3], s));
     for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
     {
         const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
@@ -346,7 +346,7 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, e->phen_dev.as<float>(), C_dev, m,
                            N, p, n);
     CUSK_HIP(e, hipGetLastError());
-    CUSK_HIP(e, hipEventRecord(e->ev[4], s));
+    CUSK_HIP(e, hipEventRecord(e->ev_corr[4], s));
     if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(mxp_host, mxp_d, sizeof(float) * m * p, hipMemcpyDeviceToHost, s));
     if (C_dev && (mxm_tri_host || pxp_tri_host))
     {
@@ -371,13 +371,13 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     }
     CUSK_HIP(e, hipStreamSynchronize(s));
     float ms = 0;
-    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[1], e->ev[2]));
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_corr[1], e->ev_corr[2]));
     e->corr_ms[0] = ms;
-    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[2], e->ev[3]));
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_corr[2], e->ev_corr[3]));
     e->corr_ms[1] = ms;
-    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[3], e->ev[4]));
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_corr[3], e->ev_corr[4]));
     e->corr_ms[2] = ms;
-    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[4]));
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_corr[0], e->ev_corr[4]));
     e->corr_ms[3] = ms;
     return CUSK_OK;
 }

@@ -12,13 +12,14 @@
 namespace cusk {
 
 constexpr int kML = CUSK_ML;
+constexpr int kLevels = CUSK_ML + 2;  // per-level device records, index = level
 constexpr unsigned long long kNone = ~0ull;
 // degree classes of the level sweep: rows whose (d+1)^2 sub-matrix fits the class
 // capacity are staged in LDS; the last class reads C from global memory.
 constexpr int kNumClasses = 5;
 constexpr int kClassCap[kNumClasses] = {31, 63, 127, 191, 1 << 30};
 constexpr int kThreads = 256;
-constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many lines' worth of slots
+constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many slots
 constexpr size_t kLdsLimit = 160 * 1024;
 
 struct DevBuf
@@ -49,22 +50,7 @@ struct DevBuf
     }
 };
 
-// small block of device counters, mirrored into pinned host memory each level
-struct LevelCounters
-{
-    int maxdeg;
-    int pad0;
-    long long total_edges;
-    long long class_items[kNumClasses];
-    unsigned long long tests;
-    unsigned long long subsets;
-    unsigned long long removed;
-    unsigned long long nrec;
-    unsigned long long qcount;      // tests queued for the exact path (may exceed the capacity)
-    unsigned long long violations;  // validate mode: certain fast verdicts contradicted by the exact path
-    int overflow;
-    int asymmetric;  // set by level 0 when C[i][j] != C[j][i] somewhere
-};
+struct LevelCounters;  // sweep_common.h
 
 }  // namespace cusk
 
@@ -81,28 +67,31 @@ struct cusk_engine
     int mode = -1;  // 0 Skeleton, 1 hetcor
     bool have_result = false;
     cusk::DevBuf adj, adj0;  // uint64 n*words: live adjacency, adjacency after level 0
-    cusk::DevBuf deg, off, nbr, best, rowinfo, binom, counters, ti;
-    cusk::DevBuf items[cusk::kNumClasses];
+    cusk::DevBuf deg, binom, counters, slots, rec_base, ti, queue, symflag;
+    // per-level working sets, ping-pong by level parity
+    cusk::DevBuf off[2], nbr[2], best[2], rowinfo[2], rowfound[2], recoff[2];
+    cusk::DevBuf items[2][cusk::kNumClasses];
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
     long long nrec = 0;
-    long long rec_cap = 0;
-    cusk::DevBuf queue, symflag, slots;
-    unsigned long long *hslots = nullptr;  // pinned
-    int *hflag = nullptr;  // pinned
-    int opt_pair = 1;
+    // pinned host mirrors
+    cusk::LevelCounters *hcnt = nullptr;   // kLevels entries
+    unsigned long long *hslots = nullptr;  // kLevels * kCounterSlots * 4
+    long long *hrec_base = nullptr;        // kLevels + 1
+    int *hflag = nullptr;
+    std::vector<unsigned long long> binom_host;
+    hipEvent_t ev_run[2] = {nullptr, nullptr};
+    hipEvent_t ev_k0[cusk::kLevels], ev_k1[cusk::kLevels], ev_l0[cusk::kLevels], ev_l1[cusk::kLevels];
+
     // options (cusk_engine_set_option)
     int opt_fast = 1;
     int opt_validate = 0;
+    int opt_pair = 1;
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
-    long long rechecks[CUSK_ML + 1] = {0};
-    long long violations = 0;
-    long long exact_fallbacks = 0;
-    cusk::LevelCounters *hcnt = nullptr;  // pinned
-    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 
     // correlation build scratch
     cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev;
+    hipEvent_t ev_corr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float corr_ms[4] = {0, 0, 0, 0};
 };
 

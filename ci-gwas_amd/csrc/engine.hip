@@ -1,0 +1,636 @@
+// engine.hip -- host side of the level sweep: the level loop and the cusk_* C ABI.
+//
+// Level loop of /root/reference/cusk/src/cuPC-S.cu:99-415 and hetcor-cuPC-S.cu:115-332,
+// restructured for one host synchronisation per level:
+//   level 0 : bitmap build (ballots), symmetry flag
+//   level l : scan of the live degrees -> CSR offsets, wave-per-row compaction + work-item
+//             count, per-class item scan, ONE sync (max degree for the termination test,
+//             item counts for the grids, previous level's recheck-queue fill),
+//             sweeps (pair / fast+recheck / exact), separating-set finalisation.
+// Degrees are maintained incrementally (every cleared adjacency bit decrements one), the
+// recheck pass reads its entry count on the device, separating-set records are placed by
+// scans (deterministic order), per-level counters live in per-level device slots and are read
+// back once at the end.  Two CSR working sets alternate by level parity so that a level
+// whose recheck queue overflowed can be redone on the exact path after the fact.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "sweep_common.h"
+
+namespace cusk {
+
+static unsigned long long binom_sat(int n, int k)
+{
+    if (k < 0 || k > n) return 0;
+    if (k > n - k) k = n - k;
+    unsigned long long r = 1;
+    const unsigned long long cap = 1ull << 62;
+    for (int i = 1; i <= k; i++)
+    {
+        unsigned long long f = (unsigned long long)(n - k + i);
+        if (r > cap / f) return cap;
+        r = r * f / (unsigned long long)i;
+    }
+    return r;
+}
+
+// loc_th of the hetcor engine when every pair has the same effective sample size:
+// the float running sum of (int)ess over (l+2)(l+1)/2 pairs, as mean_ess forms it
+// (hetcor-cuPC-S.cu:3068-3088), then th / sqrt(mean_ess - l - 3) in double (:471,:612).
+static float uniform_ess_threshold(float th, float ess, int l)
+{
+    int t;
+    if (ess != ess)
+        t = 0;
+    else if (ess >= 2147483648.0f)
+        t = 2147483647;
+    else if (ess <= -2147483648.0f)
+        t = (-2147483647 - 1);
+    else
+        t = (int)ess;
+    const int pairs = (l + 2) * (l + 1) / 2;
+    float s = 0.0f;
+    for (int i = 0; i < pairs; i++) s += (float)t;
+    const float me = s / (float)pairs;
+    return (float)((double)th / std::sqrt((double)me - (double)l - 3.0));
+}
+
+struct RunArgs
+{
+    int mode;  // 0 Skeleton, 1 hetcor
+    const float *C;
+    const float *Ness;      // hetcor, may be null (uniform)
+    float ess_uniform;      // hetcor uniform ESS
+    const int *Ginit;       // hetcor, device n*n or null
+    const float *Th;        // mode 0: host thresholds ; mode 1: Th[0] = alpha/2 quantile
+    const int *time_index;  // host, n entries or null
+    int n;
+    int maxlevel;
+};
+
+struct LevelPlan
+{
+    SweepParams sp;
+    FinalizeParams fp;
+    long long nitems[kNumClasses];
+    bool use_pair = false, use_fast = false;
+    size_t pair_lds = 0;
+    bool redone = false;
+};
+
+static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
+{
+    const int n = a.n;
+    if (n <= 0 || a.C == nullptr || a.Th == nullptr) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const int words = (n + 63) / 64;
+    e->n = n;
+    e->words = words;
+    e->mode = a.mode;
+    e->have_result = false;
+    e->nrec = 0;
+    cusk_stats local;
+    std::memset(&local, 0, sizeof(local));
+    const bool het = (a.mode == 1 && a.Ness != nullptr);
+    const int last_level = std::min(kML, a.maxlevel);
+
+    const size_t bm = sizeof(unsigned long long) * (size_t)n * words;
+    CUSK_HIP(e, e->adj.ensure(bm));
+    if (a.mode == 0) CUSK_HIP(e, e->adj0.ensure(bm));
+    CUSK_HIP(e, e->deg.ensure(sizeof(int) * (size_t)n));
+    CUSK_HIP(e, e->counters.ensure(sizeof(LevelCounters) * kLevels));
+    CUSK_HIP(e, e->slots.ensure(sizeof(unsigned long long) * kLevels * kCounterSlots * 4));
+    CUSK_HIP(e, e->rec_base.ensure(sizeof(long long) * (kLevels + 1)));
+    CUSK_HIP(e, e->symflag.ensure(sizeof(int)));
+    for (int k = 0; k < 2; k++)
+    {
+        CUSK_HIP(e, e->off[k].ensure(sizeof(int) * ((size_t)n + 1)));
+        CUSK_HIP(e, e->rowinfo[k].ensure(sizeof(RowInfo) * (size_t)n));
+        CUSK_HIP(e, e->rowfound[k].ensure(sizeof(int) * (size_t)n));
+        CUSK_HIP(e, e->recoff[k].ensure(sizeof(int) * (size_t)n));
+    }
+    LevelCounters *dcnt = e->counters.as<LevelCounters>();
+    unsigned long long *dslots = e->slots.as<unsigned long long>();
+    long long *drec_base = e->rec_base.as<long long>();
+    CUSK_HIP(e, hipMemsetAsync(dcnt, 0, sizeof(LevelCounters) * kLevels, s));
+    CUSK_HIP(e, hipMemsetAsync(dslots, 0, sizeof(unsigned long long) * kLevels * kCounterSlots * 4, s));
+    CUSK_HIP(e, hipMemsetAsync(drec_base, 0, sizeof(long long) * (kLevels + 1), s));
+    CUSK_HIP(e, hipMemsetAsync(e->symflag.p, 0, sizeof(int), s));
+    if (a.mode == 1)
+    {
+        CUSK_HIP(e, e->ti.ensure(sizeof(int) * (size_t)n));
+        if (a.time_index)
+            CUSK_HIP(e, hipMemcpyAsync(e->ti.p, a.time_index, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+        else
+            CUSK_HIP(e, hipMemsetAsync(e->ti.p, 0, sizeof(int) * (size_t)n, s));
+    }
+
+    CUSK_HIP(e, hipEventRecord(e->ev_run[0], s));
+    // ---- level 0 ----
+    CUSK_HIP(e, hipEventRecord(e->ev_l0[0], s));
+    {
+        float th0 = a.Th[0];
+        if (a.mode == 1 && !het) th0 = (float)((double)a.Th[0] / std::sqrt((double)a.ess_uniform - 3.0));
+        CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
+                                  e->symflag.as<int>(), s));
+        if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
+    }
+    CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
+    local.max_degree[0] = n - 1;
+    local.edges[0] = (long long)n * (n - 1);
+    local.tests[0] = (long long)n * (n - 1) / 2;
+    local.levels_run = 1;
+
+    LevelPlan plan[kLevels];
+    bool symmetric = false;
+    long long cap_edges = 0;  // allocation bound for the CSR arrays (edges only shrink)
+    int level_out = (a.maxlevel < 0) ? 0 : last_level + 1;
+    int levels_swept = 0;
+
+    auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
+        LevelPlan &pl = plan[l];
+        SweepParams sp = pl.sp;
+        for (int c = 0; c < kNumClasses; c++)
+        {
+            if (pl.nitems[c] <= 0) continue;
+            sp.items = e->items[l & 1][c].as<int2>();
+            sp.cap = kClassCap[c];
+            if (pl.use_pair && !exact_only)
+                CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, s));
+            else if (pl.use_fast && !exact_only)
+                CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], s));
+            else
+                CUSK_HIP(e, launch_sweep_exact(a.mode, het, l, sp, c, pl.nitems[c], s));
+        }
+        if (pl.use_fast && !exact_only) CUSK_HIP(e, launch_recheck(a.mode, het, l, sp, s));
+        return CUSK_OK;
+    };
+    auto launch_level_finalize = [&](int l) -> int {
+        if (a.mode != 0) return CUSK_OK;
+        LevelPlan &pl = plan[l];
+        CUSK_HIP(e, launch_rec_scan(e->rowfound[l & 1].as<int>(), e->recoff[l & 1].as<int>(), n, dcnt + l, drec_base, l, s));
+        CUSK_HIP(e, launch_finalize(l, pl.fp, s));
+        return CUSK_OK;
+    };
+    auto sync_counters = [&]() -> int {
+        CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
+        CUSK_HIP(e, hipStreamSynchronize(s));
+        return CUSK_OK;
+    };
+    // a level whose recheck queue overflowed is redone on the exact path (everything the fast
+    // pass recorded is a certified verdict and stays valid); returns 1 when it had to
+    auto redo_if_overflowed = [&](int l) -> int {
+        if (l < 2 || !plan[l].use_fast || plan[l].redone) return 0;
+        if (e->hcnt[l].qcount <= (unsigned long long)e->opt_queue_cap) return 0;
+        plan[l].redone = true;
+        local.exact_fallbacks++;
+        int rc = launch_level_sweeps(l, true);
+        if (rc != CUSK_OK) return -rc;
+        rc = launch_level_finalize(l);
+        if (rc != CUSK_OK) return -rc;
+        return 1;
+    };
+
+    if (last_level >= 1) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
+
+    for (int l = 1; l <= last_level; l++)
+    {
+        const int cs = l & 1;
+        CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
+        bool rebuilt = false;
+        for (;;)
+        {
+            CUSK_HIP(e, launch_scan_degrees(e->deg.as<int>(), e->off[cs].as<int>(), n, dcnt + l, s));
+            if (l == 1 && !rebuilt)
+            {
+                // sizes of the CSR arrays and of the binomial table come from the level-1 degrees
+                CUSK_HIP(e, hipMemcpyAsync(e->hflag, e->symflag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                int rc = sync_counters();
+                if (rc != CUSK_OK) return rc;
+                symmetric = (*e->hflag == 0);
+                cap_edges = std::max<long long>(e->hcnt[1].total_edges, 1);
+                const int maxdeg1 = e->hcnt[1].maxdeg;
+                for (int k = 0; k < 2; k++)
+                {
+                    CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
+                    if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
+                }
+                if (a.mode == 0)
+                {
+                    CUSK_HIP(e, e->rec_x.ensure(sizeof(int) * (size_t)cap_edges));
+                    CUSK_HIP(e, e->rec_y.ensure(sizeof(int) * (size_t)cap_edges));
+                    CUSK_HIP(e, e->rec_l.ensure(sizeof(int) * (size_t)cap_edges));
+                    CUSK_HIP(e, e->rec_z.ensure(sizeof(float) * (size_t)cap_edges));
+                    CUSK_HIP(e, e->rec_s.ensure(sizeof(int) * kML * (size_t)cap_edges));
+                }
+                e->binom_host.assign((size_t)(maxdeg1 + 1) * kBinomStride, 0ull);
+                for (int aa = 0; aa <= maxdeg1; aa++)
+                    for (int b = 0; b < kBinomStride; b++) e->binom_host[(size_t)aa * kBinomStride + b] = binom_sat(aa, b);
+                CUSK_HIP(e, e->binom.ensure(e->binom_host.size() * sizeof(unsigned long long)));
+                CUSK_HIP(e, hipMemcpyAsync(e->binom.p, e->binom_host.data(),
+                                           e->binom_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+            }
+            // which classes can be staged in LDS in this mode
+            int staged_classes = 0;
+            while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
+                staged_classes++;
+            const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+            LevelPlan &pl = plan[l];
+            pl.redone = false;
+            // level 1 on a symmetric matrix with a single threshold: pair kernel
+            const int maxdeg_bound = (l == 1) ? e->hcnt[1].maxdeg : local.max_degree[l - 1];
+            pl.pair_lds = (size_t)maxdeg_bound * 20 + 16;
+            pl.use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
+            pl.use_fast = (e->opt_fast != 0) && (l >= 2);
+            CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
+                                        a.mode == 0 ? e->best[cs].as<unsigned long long>() : nullptr,
+                                        a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,
+                                        e->binom.as<unsigned long long>(), chunk, staged_classes, pl.use_pair ? 1 : 0,
+                                        e->rowinfo[cs].as<RowInfo>(), dcnt + l, s));
+            CUSK_HIP(e, launch_item_scan(e->rowinfo[cs].as<RowInfo>(), n, dcnt + l, s));
+            int rc = sync_counters();  // the level's one host synchronisation
+            if (rc != CUSK_OK) return rc;
+            // did the previous level's recheck queue overflow?  then redo it and rebuild this level
+            const int redo = redo_if_overflowed(l - 1);
+            if (redo < 0) return -redo;
+            if (redo == 1)
+            {
+                rebuilt = true;
+                continue;
+            }
+            break;
+        }
+        const LevelCounters &hc = e->hcnt[l];
+        local.max_degree[l] = hc.maxdeg;
+        local.edges[l] = hc.total_edges;
+        if (hc.maxdeg - 1 < l)
+        {  // cuPC-S.cu:154-159
+            level_out = l - 1;
+            break;
+        }
+        if (hc.overflow)
+            return fail(e, CUSK_ERR_OVERFLOW,
+                        "C(degree, level) exceeds 2^62 at level " + std::to_string(l) + " (max degree " +
+                            std::to_string(hc.maxdeg) + ")");
+        LevelPlan &pl = plan[l];
+        int2 *iptr[kNumClasses];
+        for (int c = 0; c < kNumClasses; c++)
+        {
+            pl.nitems[c] = hc.class_items[c];
+            CUSK_HIP(e, e->items[cs][c].ensure(sizeof(int2) * (size_t)std::max<long long>(pl.nitems[c], 1)));
+            iptr[c] = e->items[cs][c].as<int2>();
+        }
+        CUSK_HIP(e, launch_fill_items(e->rowinfo[cs].as<RowInfo>(), n, iptr, s));
+
+        SweepParams &sp = pl.sp;
+        sp.C = a.C;
+        sp.Ness = a.Ness;
+        sp.n = n;
+        sp.level = l;
+        sp.off = e->off[cs].as<int>();
+        sp.nbr = e->nbr[cs].as<int>();
+        sp.best = e->best[cs].as<unsigned long long>();
+        sp.rowfound = e->rowfound[cs].as<int>();
+        sp.adj = e->adj.as<unsigned long long>();
+        sp.deg = e->deg.as<int>();
+        sp.words = words;
+        sp.items = nullptr;
+        sp.binom = e->binom.as<unsigned long long>();
+        sp.time_index = e->ti.as<int>();
+        sp.chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+        sp.cap = 0;
+        sp.cnt = dcnt + l;
+        sp.slots = dslots + (size_t)l * kCounterSlots * 4;
+        if (a.mode == 0)
+            sp.th = a.Th[l];
+        else if (het)
+            sp.th = a.Th[0];
+        else
+            sp.th = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
+        {
+            const double tq = std::tanh((double)sp.th);
+            sp.t2 = (float)(tq * tq);
+        }
+        sp.queue = nullptr;
+        sp.qcap = 0;
+        if (pl.use_fast)
+        {
+            CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
+            sp.queue = e->queue.as<RecheckEntry>();
+            sp.qcap = (unsigned long long)e->opt_queue_cap;
+        }
+        FinalizeParams &fp = pl.fp;
+        fp.C = a.C;
+        fp.n = n;
+        fp.off = sp.off;
+        fp.nbr = sp.nbr;
+        fp.best = sp.best;
+        fp.recoff = e->recoff[cs].as<int>();
+        fp.rec_base = drec_base;
+        fp.level = l;
+        fp.adj = sp.adj;
+        fp.deg = sp.deg;
+        fp.words = words;
+        fp.binom = sp.binom;
+        fp.rec_x = e->rec_x.as<int>();
+        fp.rec_y = e->rec_y.as<int>();
+        fp.rec_l = e->rec_l.as<int>();
+        fp.rec_s = e->rec_s.as<int>();
+        fp.rec_z = e->rec_z.as<float>();
+
+        CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
+        int rc = launch_level_sweeps(l, false);
+        if (rc != CUSK_OK) return rc;
+        CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
+        rc = launch_level_finalize(l);
+        if (rc != CUSK_OK) return rc;
+        CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
+        levels_swept = l;
+        local.levels_run++;
+    }
+
+    // final read-back (and a late overflow check for the last level that ran)
+    for (;;)
+    {
+        int rc = sync_counters();
+        if (rc != CUSK_OK) return rc;
+        const int redo = redo_if_overflowed(levels_swept);
+        if (redo < 0) return -redo;
+        if (redo == 0) break;
+    }
+    CUSK_HIP(e, hipMemcpyAsync(e->hslots, dslots, sizeof(unsigned long long) * kLevels * kCounterSlots * 4,
+                               hipMemcpyDeviceToHost, s));
+    CUSK_HIP(e, hipMemcpyAsync(e->hrec_base, drec_base, sizeof(long long) * (kLevels + 1), hipMemcpyDeviceToHost, s));
+    CUSK_HIP(e, hipEventRecord(e->ev_run[1], s));
+    CUSK_HIP(e, hipStreamSynchronize(s));
+    float ms = 0.0f;
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[0], e->ev_l1[0]));
+    local.kernel_ms[0] = local.level_ms[0] = ms;
+    for (int l = 1; l <= levels_swept; l++)
+    {
+        for (int k = 0; k < kCounterSlots; k++)
+        {
+            const unsigned long long *sl = e->hslots + ((size_t)l * kCounterSlots + k) * 4;
+            local.tests[l] += (long long)sl[0];
+            local.subsets[l] += (long long)sl[1];
+            local.removed[l] += (long long)sl[2];
+            local.violations += (long long)sl[3];
+        }
+        local.rechecks[l] = (long long)e->hcnt[l].qcount;
+        CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_k0[l], e->ev_k1[l]));
+        local.kernel_ms[l] = ms;
+        CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[l], e->ev_l1[l]));
+        local.level_ms[l] = ms;
+    }
+    CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_run[0], e->ev_run[1]));
+    local.total_ms = ms;
+    local.level = level_out;
+    if (a.mode == 0) e->nrec = e->hrec_base[levels_swept + 1];
+    e->have_result = true;
+    if (st) *st = local;
+    return CUSK_OK;
+}
+
+}  // namespace cusk
+
+using namespace cusk;
+
+// ---------------------------------------------------------------------------
+// C ABI: engine
+// ---------------------------------------------------------------------------
+
+extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
+{
+    if (!out) return CUSK_ERR_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    {
+        std::fprintf(stderr, "libcusk_hip: no HIP device available (this library has no CPU fallback)\n");
+        return CUSK_ERR_HIP;
+    }
+    if (device < 0 || device >= ndev) return CUSK_ERR_ARG;
+    if (hipSetDevice(device) != hipSuccess) return CUSK_ERR_HIP;
+    cusk_engine *e = new cusk_engine();
+    e->device = device;
+    for (int l = 0; l < kLevels; l++) e->ev_k0[l] = e->ev_k1[l] = e->ev_l0[l] = e->ev_l1[l] = nullptr;
+    bool ok = true;
+    if (stream)
+    {
+        e->stream = reinterpret_cast<hipStream_t>(stream);
+        e->own_stream = false;
+    }
+    else
+    {
+        ok = ok && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
+        e->own_stream = ok;
+    }
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hcnt), sizeof(LevelCounters) * kLevels) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hslots),
+                             sizeof(unsigned long long) * kLevels * kCounterSlots * 4) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hrec_base), sizeof(long long) * (kLevels + 1)) == hipSuccess;
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;
+    for (auto &ev : e->ev_run) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    for (auto &ev : e->ev_corr) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    for (int l = 0; l < kLevels; l++)
+    {
+        ok = ok && hipEventCreate(&e->ev_k0[l]) == hipSuccess && hipEventCreate(&e->ev_k1[l]) == hipSuccess;
+        ok = ok && hipEventCreate(&e->ev_l0[l]) == hipSuccess && hipEventCreate(&e->ev_l1[l]) == hipSuccess;
+    }
+    if (!ok)
+    {
+        cusk_engine_destroy(e);
+        return CUSK_ERR_HIP;
+    }
+    *out = e;
+    return CUSK_OK;
+}
+
+extern "C" void cusk_engine_destroy(cusk_engine *e)
+{
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->slots, &e->rec_base, &e->ti, &e->queue,
+                      &e->symflag, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
+        b->release();
+    for (int k = 0; k < 2; k++)
+    {
+        for (DevBuf *b : {&e->off[k], &e->nbr[k], &e->best[k], &e->rowinfo[k], &e->rowfound[k], &e->recoff[k]}) b->release();
+        for (auto &b : e->items[k]) b.release();
+    }
+    if (e->hcnt) (void)hipHostFree(e->hcnt);
+    if (e->hslots) (void)hipHostFree(e->hslots);
+    if (e->hrec_base) (void)hipHostFree(e->hrec_base);
+    if (e->hflag) (void)hipHostFree(e->hflag);
+    for (auto &ev : e->ev_run)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->ev_corr)
+        if (ev) (void)hipEventDestroy(ev);
+    for (int l = 0; l < kLevels; l++)
+        for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
+            if (ev) (void)hipEventDestroy(ev);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long value)
+{
+    if (!e || !key) return CUSK_ERR_ARG;
+    const std::string k(key);
+    if (k == "fast")
+        e->opt_fast = (int)value;
+    else if (k == "validate")
+        e->opt_validate = (int)value;
+    else if (k == "pair")
+        e->opt_pair = (int)value;
+    else if (k == "queue_capacity" && value > 0)
+        e->opt_queue_cap = value;
+    else if (k == "chunk" && value >= 256)
+        e->opt_chunk = value;
+    else
+        return fail(e, CUSK_ERR_ARG, "unknown option " + k);
+    return CUSK_OK;
+}
+
+extern "C" const char *cusk_last_error(const cusk_engine *e) { return e ? e->err.c_str() : "no engine"; }
+extern "C" void *cusk_engine_stream(const cusk_engine *e) { return e ? (void *)e->stream : nullptr; }
+
+extern "C" int cusk_run_skeleton(cusk_engine *e, const float *C_dev, int n, const float *Th, int maxlevel,
+                                 cusk_stats *stats)
+{
+    if (!e) return CUSK_ERR_ARG;
+    RunArgs a{};
+    a.mode = 0;
+    a.C = C_dev;
+    a.Th = Th;
+    a.n = n;
+    a.maxlevel = maxlevel;
+    return run_levels(e, a, stats);
+}
+
+extern "C" int cusk_run_hetcor(cusk_engine *e, const float *C_dev, const float *N_dev, float ess_uniform,
+                               const int *G_init_dev, int n, float th, int maxlevel, const int *time_index,
+                               cusk_stats *stats)
+{
+    if (!e) return CUSK_ERR_ARG;
+    RunArgs a{};
+    a.mode = 1;
+    a.C = C_dev;
+    a.Ness = N_dev;
+    a.ess_uniform = ess_uniform;
+    a.Ginit = G_init_dev;
+    float thv[1] = {th};
+    a.Th = thv;
+    a.time_index = time_index;
+    a.n = n;
+    a.maxlevel = maxlevel;
+    return run_levels(e, a, stats);
+}
+
+extern "C" int cusk_result_n(const cusk_engine *e) { return (e && e->have_result) ? e->n : 0; }
+extern "C" int cusk_result_words(const cusk_engine *e) { return (e && e->have_result) ? e->words : 0; }
+extern "C" const uint64_t *cusk_result_adj_bits_dev(const cusk_engine *e)
+{
+    return (e && e->have_result) ? reinterpret_cast<const uint64_t *>(e->adj.p) : nullptr;
+}
+
+extern "C" int cusk_result_adj_i32_dev(cusk_engine *e, int *G_dev)
+{
+    if (!e || !e->have_result) return fail(e, CUSK_ERR_STATE, "no result");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    CUSK_HIP(e, launch_expand_adj(e->adj.as<unsigned long long>(), G_dev, e->n, e->words, e->stream));
+    CUSK_HIP(e, hipStreamSynchronize(e->stream));
+    return CUSK_OK;
+}
+
+extern "C" int cusk_result_adj_i32(cusk_engine *e, int *G_host)
+{
+    if (!e || !e->have_result) return fail(e, CUSK_ERR_STATE, "no result");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t bytes = sizeof(int) * (size_t)e->n * e->n;
+    int *tmp = nullptr;
+    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
+    int rc = cusk_result_adj_i32_dev(e, tmp);
+    if (rc == CUSK_OK)
+    {
+        hipError_t st = hipMemcpy(G_host, tmp, bytes, hipMemcpyDeviceToHost);
+        if (st != hipSuccess) rc = fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    }
+    (void)hipFree(tmp);
+    return rc;
+}
+
+extern "C" int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_host)
+{
+    if (!e || !e->have_result || e->mode != 0) return fail(e, CUSK_ERR_STATE, "no Skeleton result");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t bytes = sizeof(float) * (size_t)e->n * e->n;
+    float *tmp = nullptr;
+    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
+    hipError_t st = launch_expand_pmax(e->adj.as<unsigned long long>(), e->adj0.as<unsigned long long>(), C_dev, tmp, e->n,
+                                       e->words, e->rec_x.as<int>(), e->rec_y.as<int>(), e->rec_z.as<float>(), e->nrec,
+                                       e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(pMax_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    return CUSK_OK;
+}
+
+extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
+{
+    if (!e || !e->have_result || e->mode != 0) return fail(e, CUSK_ERR_STATE, "no Skeleton result");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t count = (size_t)e->n * e->n * kML;
+    // the dense n*n*14 array exists only for the reference's ABI; it is filled on the host
+    std::fill(SepSet_host, SepSet_host + count, -1);
+    if (e->nrec > 0)
+    {
+        std::vector<int> x(e->nrec), y(e->nrec), S((size_t)e->nrec * kML);
+        CUSK_HIP(e, hipMemcpy(x.data(), e->rec_x.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
+        CUSK_HIP(e, hipMemcpy(y.data(), e->rec_y.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
+        CUSK_HIP(e, hipMemcpy(S.data(), e->rec_s.p, sizeof(int) * kML * e->nrec, hipMemcpyDeviceToHost));
+        for (long long r = 0; r < e->nrec; r++)
+            std::memcpy(SepSet_host + ((size_t)x[r] * e->n + y[r]) * kML, S.data() + (size_t)r * kML, sizeof(int) * kML);
+    }
+    return CUSK_OK;
+}
+
+extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *level, float *z, int *S)
+{
+    if (!e || !e->have_result || e->mode != 0) return -1;
+    if (hipSetDevice(e->device) != hipSuccess) return -1;
+    const long long c = e->nrec;
+    if (c > 0)
+    {
+        if (x && hipMemcpy(x, e->rec_x.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (y && hipMemcpy(y, e->rec_y.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (level && hipMemcpy(level, e->rec_l.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (z && hipMemcpy(z, e->rec_z.p, sizeof(float) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (S && hipMemcpy(S, e->rec_s.p, sizeof(int) * kML * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    }
+    return c;
+}
+
+extern "C" void *cusk_dev_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return nullptr;
+    return p;
+}
+extern "C" void cusk_dev_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}
+extern "C" int cusk_dev_upload(void *dst, const void *src, size_t bytes)
+{
+    return hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice) == hipSuccess ? CUSK_OK : CUSK_ERR_HIP;
+}
+extern "C" int cusk_dev_download(void *dst, const void *src, size_t bytes)
+{
+    return hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost) == hipSuccess ? CUSK_OK : CUSK_ERR_HIP;
+}

@@ -1,0 +1,162 @@
+// sweep_common.h -- structures and device helpers shared by the level-sweep translation units.
+#pragma once
+#include "cusk_internal.h"
+
+namespace cusk {
+
+constexpr int kBinomStride = 16;  // binom[a * 16 + b] = C(a, b), b <= 15, saturating at 2^62
+
+struct RowInfo
+{
+    int cls;      // degree class, -1 = no work this level
+    int base;     // first work item of the row inside its class list
+    int nchunks;  // number of work items
+    int pad;
+};
+
+struct RecheckEntry
+{
+    int x;
+    int k2;
+    unsigned long long rank;
+};
+
+// One per level, device resident; the whole array is mirrored to pinned host memory at each sync.
+struct LevelCounters
+{
+    int maxdeg;
+    int overflow;  // C(d, l) >= 2^62 somewhere
+    long long total_edges;
+    long long class_items[kNumClasses];
+    unsigned long long qcount;     // tests queued for the exact path (may exceed the capacity)
+    unsigned long long rec_total;  // separating-set records produced by this level
+};
+
+struct SweepParams
+{
+    const float *C;
+    const float *Ness;  // per-pair effective sample sizes (HET) or nullptr
+    int n;
+    int level;
+    const int *off;
+    const int *nbr;
+    unsigned long long *best;  // MODE 0: lowest passing rank per CSR slot
+    int *rowfound;             // MODE 0: number of slots of the row that got a separating set
+    unsigned long long *adj;   // live adjacency bitmap
+    int *deg;                  // live degrees (decremented whenever an adjacency bit is cleared)
+    int words;
+    const int2 *items;
+    const unsigned long long *binom;
+    const int *time_index;  // MODE 1, device, n entries
+    float th;               // MODE 0: Th[l]; MODE 1 uniform ESS: th/sqrt(mean_ess-l-3); HET: alpha/2 quantile
+    float t2;               // tanh(th)^2 for the fixed-threshold fast filter
+    unsigned long long chunk;
+    int cap;  // class capacity (LDS carve), ignored when !STAGED
+    LevelCounters *cnt;         // this level's counters
+    unsigned long long *slots;  // this level's kCounterSlots x 4 spread counters: tests, subsets, removed, violations
+    RecheckEntry *queue;
+    unsigned long long qcap;
+};
+
+struct FinalizeParams
+{
+    const float *C;
+    int n;
+    const int *off;
+    const int *nbr;
+    const unsigned long long *best;
+    const int *recoff;  // exclusive scan of rowfound
+    const long long *rec_base;  // [level] = records of all earlier levels
+    int level;
+    unsigned long long *adj;
+    int *deg;
+    int words;
+    const unsigned long long *binom;
+    int *rec_x, *rec_y, *rec_l, *rec_s;
+    float *rec_z;
+};
+
+__host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
+
+// LDS carve of the staged sweep kernels for a class capacity
+struct LdsLayout
+{
+    size_t nbr, best, ti, sub, ess, total;
+};
+__host__ __device__ inline LdsLayout lds_layout(int cap, bool het)
+{
+    LdsLayout l;
+    size_t ld = (size_t)((cap + 1) | 1);
+    l.nbr = 0;
+    l.best = align16(l.nbr + sizeof(int) * (cap + 1));
+    l.ti = align16(l.best + sizeof(unsigned long long) * cap);
+    l.sub = align16(l.ti + sizeof(int) * (cap + 1));
+    l.ess = align16(l.sub + sizeof(float) * (cap + 1) * ld);
+    l.total = het ? align16(l.ess + sizeof(float) * (cap + 1) * ld) : l.ess;
+    return l;
+}
+
+#if defined(__HIPCC__)
+// mean_ess of hetcor-cuPC-S.cu:3068-3088: entries truncated to int (v_cvt_i32_f32
+// saturates and maps NaN to 0, as the reference's GPU does)
+__device__ __forceinline__ float ess_term(float e) { return (float)(int)e; }
+
+// unrank a 0-based lexicographic combination rank into ascending positions idx[0..L) out of d
+template <int L>
+__device__ __forceinline__ void unrank_comb(unsigned long long rem, int d, const unsigned long long *__restrict__ binom,
+                                            int *idx)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        while (true)
+        {
+            unsigned long long b = binom[(size_t)(d - 1 - c) * kBinomStride + (L - 1 - i)];
+            if (rem < b) break;
+            rem -= b;
+            c++;
+        }
+        idx[i] = c;
+        c++;
+    }
+}
+
+// clear the edge X - Y in both directions; every bit that this call flips lowers a degree once
+__device__ __forceinline__ bool clear_edge(unsigned long long *adj, int *deg, int words, int X, int Y)
+{
+    const unsigned long long o1 = atomicAnd(&adj[(size_t)X * words + (Y >> 6)], ~(1ull << (Y & 63)));
+    const unsigned long long o2 = atomicAnd(&adj[(size_t)Y * words + (X >> 6)], ~(1ull << (X & 63)));
+    const bool f1 = (o1 >> (Y & 63)) & 1ull, f2 = (o2 >> (X & 63)) & 1ull;
+    if (f1) atomicSub(&deg[X], 1);
+    if (f2) atomicSub(&deg[Y], 1);
+    return f1;
+}
+#endif
+
+// ---- launchers (one translation unit each) ----
+// sweep_exact.hip
+hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st);
+hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st);
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st);
+// sweep_fast.hip
+hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
+                             hipStream_t st);
+// sweep_level.hip: level 0, compaction, level-1 pair kernel, result expansion
+hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
+                         float th, int *asym_flag, hipStream_t st);
+hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
+hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *cnt, hipStream_t st);
+hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
+                           int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
+                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, hipStream_t st);
+hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st);
+hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
+hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
+                           hipStream_t st);
+hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
+hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);
+hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,
+                              int n, int words, const int *x, const int *y, const float *z, long long nrec, hipStream_t st);
+
+}  // namespace cusk

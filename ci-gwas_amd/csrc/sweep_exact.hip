@@ -1,0 +1,300 @@
+// sweep_exact.hip -- the level sweep, the recheck pass and the finaliser on the EXACT path
+// (ci_exact.h: the reference's fp32 operation order).
+//
+// sweep_kernel is the complete level-l kernel (cuPC-S.cu cal_Indepl1..14,
+// hetcor-cuPC-S.cu cal_Indepl1_ess..14_ess): it is what runs when the fast filter is switched
+// off, for level 1 on asymmetric / heterogeneous-ESS inputs, and as the fallback when the
+// recheck queue overflows.  recheck_kernel evaluates the tests the fast filter could not
+// certify; finalize_kernel turns the selected ranks into sparse separating-set records.
+#include "ci_exact.h"
+#include "sweep_stage.h"
+
+namespace cusk {
+
+template <int L, int MODE, bool HET, bool STAGED>
+__global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[4];
+    const int2 item = p.items[blockIdx.x];
+    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    rv.stage();
+    const int d = rv.d;
+    const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + L], item.y, p.chunk);
+
+    unsigned long long ntests = 0, nsub = 0, nrem = 0;
+    if (rr.lo < rr.hi)
+    {
+        int idx[L];
+        unrank_comb<L>(rr.lo, d, p.binom, idx);
+        for (unsigned long long rank = rr.lo; rank < rr.hi; rank++)
+        {
+            float m2[(L > 1) ? L * L : 1], m1x[L];
+#pragma unroll
+            for (int a = 0; a < L; a++) m1x[a] = rv.cval(d, idx[a]);
+            if constexpr (L >= 2)
+            {
+#pragma unroll
+                for (int a = 0; a < L; a++)
+#pragma unroll
+                    for (int b = 0; b < L; b++)
+                        m2[a * L + b] = (a == b) ? 1.0f : (a < b ? rv.cval(idx[a], idx[b]) : rv.cval(idx[b], idx[a]));
+            }
+            SubsetExact<L> cx;
+            cx.prepare(m2, m1x);
+            nsub++;
+            [[maybe_unused]] int tmaxS = 0;
+            if constexpr (MODE == 1)
+            {
+                tmaxS = rv.tix(idx[0]);
+#pragma unroll
+                for (int a = 1; a < L; a++) tmaxS = max(tmaxS, rv.tix(idx[a]));
+            }
+            bool anyalive = false;
+            for (int k2 = 0; k2 < d; k2++)
+            {
+                const bool live = rv.live(k2, rank);
+                anyalive |= live;
+                if (!live) continue;
+                bool inS = false;
+#pragma unroll
+                for (int a = 0; a < L; a++) inS |= (idx[a] == k2);
+                if (inS) continue;
+                if constexpr (MODE == 1)
+                {
+                    if (tmaxS > max(rv.tix(d), rv.tix(k2))) continue;
+                }
+                float m1y[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) m1y[a] = rv.cval(k2, idx[a]);
+                const float rho = cx.rho(rv.cval(d, k2), m1y);
+                ntests++;
+                float lth = p.th;
+                if constexpr (HET) lth = rv.template ess_threshold_exact<L>(k2, idx);
+                if (z_below<L == 1>(rho, lth))
+                    if (rv.separate(k2, rank)) nrem++;
+            }
+            if (!anyalive) break;
+            if (!next_comb<L>(idx, d)) break;
+        }
+    }
+    flush_counters(s_cnt, p.slots, ntests, nsub, nrem, 0ull);
+}
+
+template <int L, int MODE, bool HET>
+static hipError_t launch_exact_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    if (nitems <= 0) return hipSuccess;
+    if (cls < kNumClasses - 1)
+    {
+        const size_t lds = lds_layout(kClassCap[cls], HET).total;
+        auto kfn = sweep_kernel<L, MODE, HET, true>;
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    }
+    else
+    {
+        hipLaunchKernelGGL((sweep_kernel<L, MODE, HET, false>), dim3((unsigned)nitems), dim3(kThreads), 16, st, p);
+    }
+    return hipGetLastError();
+}
+
+#define CUSK_FOR_LEVELS(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14)
+
+hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                               \
+    case LL:                                                                        \
+        if (mode == 0) return launch_exact_L<LL, 0, false>(p, cls, nitems, st);     \
+        return het ? launch_exact_L<LL, 1, true>(p, cls, nitems, st)                \
+                   : launch_exact_L<LL, 1, false>(p, cls, nitems, st);
+        CUSK_FOR_LEVELS(CUSK_CASE)
+#undef CUSK_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+// ---------------------------------------------------------------------------
+// exact evaluation of the queued tests: one lane per entry, operands straight from HBM/L2;
+// the entry count is read on the device (no host round trip), grid-stride loop
+// ---------------------------------------------------------------------------
+template <int L, int MODE, bool HET>
+__global__ void __launch_bounds__(256) recheck_kernel(SweepParams p)
+{
+    const unsigned long long count = min(p.cnt->qcount, p.qcap);
+    const int n = p.n;
+    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+         e += (unsigned long long)gridDim.x * blockDim.x)
+    {
+        const RecheckEntry en = p.queue[e];
+        const int X = en.x, k2 = en.k2;
+        const int o0 = p.off[X];
+        const int d = p.off[X + 1] - o0;
+        int idx[L];
+        unrank_comb<L>(en.rank, d, p.binom, idx);
+        const int Y = p.nbr[o0 + k2];
+        int S[L];
+#pragma unroll
+        for (int a = 0; a < L; a++) S[a] = p.nbr[o0 + idx[a]];
+        float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
+#pragma unroll
+        for (int a = 0; a < L; a++)
+        {
+            m1x[a] = p.C[(size_t)X * n + S[a]];
+            m1y[a] = p.C[(size_t)Y * n + S[a]];
+        }
+        if constexpr (L >= 2)
+        {
+#pragma unroll
+            for (int a = 0; a < L; a++)
+#pragma unroll
+                for (int b = 0; b < L; b++)
+                    m2[a * L + b] =
+                        (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
+        }
+        SubsetExact<L> cx;
+        cx.prepare(m2, m1x);
+        const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
+        float lth = p.th;
+        if constexpr (HET)
+        {
+            float s = 0.0f;
+            s += ess_term(p.Ness[(size_t)Y * n + X]);
+#pragma unroll
+            for (int a = 0; a < L; a++)
+            {
+                s += ess_term(p.Ness[(size_t)S[a] * n + X]);
+                s += ess_term(p.Ness[(size_t)S[a] * n + Y]);
+#pragma unroll
+                for (int b = 0; b < a; b++) s += ess_term(p.Ness[(size_t)S[a] * n + S[b]]);
+            }
+            const float me = s / (float)((L + 2) * (L + 1) / 2);
+            lth = (float)((double)p.th / sqrt((double)me - (double)L - 3.0));
+        }
+        if (z_below<L == 1>(rho, lth))
+        {
+            bool first;
+            if constexpr (MODE == 0)
+            {
+                const unsigned long long old = atomicMin(&p.best[o0 + k2], en.rank);
+                first = (old == kNone);
+                if (first) atomicAdd(&p.rowfound[X], 1);
+            }
+            else
+            {
+                first = clear_edge(p.adj, p.deg, p.words, X, Y);
+            }
+            if (first) atomicAdd(&p.slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], 1ull);
+        }
+    }
+}
+
+hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st)
+{
+    const dim3 grid(512), block(256);
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                                             \
+    case LL:                                                                                      \
+        if (mode == 0)                                                                            \
+            hipLaunchKernelGGL((recheck_kernel<LL, 0, false>), grid, block, 0, st, p);            \
+        else if (het)                                                                             \
+            hipLaunchKernelGGL((recheck_kernel<LL, 1, true>), grid, block, 0, st, p);             \
+        else                                                                                      \
+            hipLaunchKernelGGL((recheck_kernel<LL, 1, false>), grid, block, 0, st, p);            \
+        break;
+        CUSK_FOR_LEVELS(CUSK_CASE)
+#undef CUSK_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// Skeleton mode: selected ranks -> sparse separating-set records.  One wave per row; the
+// record index is rec_base[level] + recoff[row] + (number of earlier selected slots of the
+// row), so records are ordered by (level, X, position of Y) without any atomics.  The winner's
+// Fisher z is recomputed on the exact path (pMax does not depend on which lane found it) and
+// the edge is cleared in both directions.
+// ---------------------------------------------------------------------------
+template <int L>
+__global__ void finalize_kernel(FinalizeParams p)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= p.n) return;
+    const int o0 = p.off[row];
+    const int d = p.off[row + 1] - o0;
+    const int n = p.n;
+    long long next = p.rec_base[p.level] + p.recoff[row];
+    for (int k0 = 0; k0 < d; k0 += 64)
+    {
+        const int k = k0 + lane;
+        const unsigned long long r = (k < d) ? p.best[o0 + k] : kNone;
+        const unsigned long long has = __ballot(r != kNone);
+        if (has == 0ull) continue;
+        const long long slot = next + __popcll(has & ((1ull << lane) - 1ull));
+        next += __popcll(has);
+        if (r == kNone) continue;
+        int idx[L];
+        unrank_comb<L>(r, d, p.binom, idx);
+        const int X = row, Y = p.nbr[o0 + k];
+        int S[L];
+#pragma unroll
+        for (int a = 0; a < L; a++) S[a] = p.nbr[o0 + idx[a]];
+        float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
+#pragma unroll
+        for (int a = 0; a < L; a++)
+        {
+            m1x[a] = p.C[(size_t)X * n + S[a]];
+            m1y[a] = p.C[(size_t)Y * n + S[a]];
+        }
+        if constexpr (L >= 2)
+        {
+#pragma unroll
+            for (int a = 0; a < L; a++)
+#pragma unroll
+                for (int b = 0; b < L; b++)
+                    m2[a * L + b] =
+                        (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
+        }
+        SubsetExact<L> cx;
+        cx.prepare(m2, m1x);
+        const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
+        float z;
+        (void)z_below<L == 1>(rho, 0.0f, &z);
+        p.rec_x[slot] = X;
+        p.rec_y[slot] = Y;
+        p.rec_l[slot] = L;
+        p.rec_z[slot] = z;
+#pragma unroll
+        for (int a = 0; a < kML; a++) p.rec_s[slot * kML + a] = (a < L) ? S[a < L ? a : 0] : -1;
+        (void)clear_edge(p.adj, p.deg, p.words, X, Y);
+    }
+}
+
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
+{
+    const dim3 grid((p.n + 3) / 4), block(256);
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                   \
+    case LL:                                                            \
+        hipLaunchKernelGGL(finalize_kernel<LL>, grid, block, 0, st, p); \
+        break;
+        CUSK_FOR_LEVELS(CUSK_CASE)
+#undef CUSK_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace cusk

@@ -1,0 +1,204 @@
+// sweep_fast.hip -- level sweep for l >= 2 through the register-Cholesky filter (ci_fast.h).
+//
+// Same tiling, LDS staging, lane <-> conditioning-set mapping and selection rule as the exact
+// sweep_kernel; every test is first judged by the filter, certified verdicts are applied at
+// once and the uncertain remainder is queued for recheck_kernel (exact path).  VALIDATE also
+// runs the exact arithmetic on every certified verdict and counts contradictions.
+#include "ci_exact.h"
+#include "ci_fast.h"
+#include "sweep_stage.h"
+
+namespace cusk {
+
+template <int L, int MODE, bool HET, bool STAGED, bool VALIDATE>
+__global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
+{
+    static_assert(L >= 2, "level 1 has its own kernels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[4];
+    const int2 item = p.items[blockIdx.x];
+    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    rv.stage();
+    const int d = rv.d;
+    const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + L], item.y, p.chunk);
+
+    unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
+    if (rr.lo < rr.hi)
+    {
+        int idx[L];
+        unrank_comb<L>(rr.lo, d, p.binom, idx);
+        for (unsigned long long rank = rr.lo; rank < rr.hi; rank++)
+        {
+            float cl[SubsetFast<L>::NL], m1x[L];
+#pragma unroll
+            for (int a = 0; a < L; a++) m1x[a] = rv.cval(d, idx[a]);
+#pragma unroll
+            for (int a = 1; a < L; a++)
+#pragma unroll
+                for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = rv.cval(idx[b], idx[a]);
+            SubsetFast<L> fx;
+            fx.prepare(cl, m1x);
+            nsub++;
+            [[maybe_unused]] SubsetExact<L> cx;
+            if constexpr (VALIDATE)
+            {
+                float m2[L * L];
+#pragma unroll
+                for (int a = 0; a < L; a++)
+#pragma unroll
+                    for (int b = 0; b < L; b++)
+                        m2[a * L + b] = (a == b) ? 1.0f : (a < b ? rv.cval(idx[a], idx[b]) : rv.cval(idx[b], idx[a]));
+                cx.prepare(m2, m1x);
+            }
+            [[maybe_unused]] int tmaxS = 0;
+            [[maybe_unused]] float essS = 0.0f;
+            if constexpr (MODE == 1)
+            {
+                tmaxS = rv.tix(idx[0]);
+#pragma unroll
+                for (int a = 1; a < L; a++) tmaxS = max(tmaxS, rv.tix(idx[a]));
+            }
+            if constexpr (HET)
+            {
+                // filter-only estimate of the subset's share of mean_ess (summation order is free here)
+#pragma unroll
+                for (int a = 0; a < L; a++)
+                {
+                    essS += ess_term(rv.eval(idx[a], d));
+#pragma unroll
+                    for (int b = 0; b < a; b++) essS += ess_term(rv.eval(idx[a], idx[b]));
+                }
+            }
+            bool anyalive = false;
+            for (int k2 = 0; k2 < d; k2++)
+            {
+                const bool live = rv.live(k2, rank);
+                anyalive |= live;
+                if (!live) continue;
+                bool inS = false;
+#pragma unroll
+                for (int a = 0; a < L; a++) inS |= (idx[a] == k2);
+                if (inS) continue;
+                if constexpr (MODE == 1)
+                {
+                    if (tmaxS > max(rv.tix(d), rv.tix(k2))) continue;
+                }
+                ntests++;
+                int v = kUnsure;
+                float m1y[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) m1y[a] = rv.cval(k2, idx[a]);
+                const float m0 = rv.cval(d, k2);
+                if (!fx.ill)
+                {
+                    if constexpr (HET)
+                    {
+                        float s = essS + ess_term(rv.eval(k2, d));
+#pragma unroll
+                        for (int a = 0; a < L; a++) s += ess_term(rv.eval(idx[a], k2));
+                        const float me = s / (float)((L + 2) * (L + 1) / 2);
+                        v = fx.verdict_z(m0, m1y, p.th * __frsqrt_rn(me - (float)(L + 3)));
+                    }
+                    else
+                    {
+                        v = fx.verdict_fixed(m0, m1y, p.t2);
+                    }
+                }
+                if constexpr (VALIDATE)
+                {
+                    if (v != kUnsure)
+                    {
+                        float lth = p.th;
+                        if constexpr (HET) lth = rv.template ess_threshold_exact<L>(k2, idx);
+                        const bool ex = z_below<false>(cx.rho(m0, m1y), lth);
+                        if (ex != (v == kPass)) nbad++;
+                    }
+                }
+                if (v == kUnsure)
+                {
+                    const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
+                    if (qi < p.qcap)
+                    {
+                        RecheckEntry en;
+                        en.x = rv.X;
+                        en.k2 = k2;
+                        en.rank = rank;
+                        p.queue[qi] = en;
+                    }
+                }
+                else if (v == kPass)
+                {
+                    if (rv.separate(k2, rank)) nrem++;
+                }
+            }
+            if (!anyalive) break;
+            if (!next_comb<L>(idx, d)) break;
+        }
+    }
+    flush_counters(s_cnt, p.slots, ntests, nsub, nrem, nbad);
+}
+
+template <int L, int MODE, bool HET, bool VALIDATE>
+static hipError_t launch_fast_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    if (nitems <= 0) return hipSuccess;
+    if (cls < kNumClasses - 1)
+    {
+        const size_t lds = lds_layout(kClassCap[cls], HET).total;
+        auto kfn = sweep_fast_kernel<L, MODE, HET, true, VALIDATE>;
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    }
+    else
+    {
+        hipLaunchKernelGGL((sweep_fast_kernel<L, MODE, HET, false, VALIDATE>), dim3((unsigned)nitems), dim3(kThreads), 16, st,
+                           p);
+    }
+    return hipGetLastError();
+}
+
+template <int L>
+static hipError_t launch_fast_level(int mode, bool het, bool validate, const SweepParams &p, int cls, long long nitems,
+                                    hipStream_t st)
+{
+    if (validate)
+    {
+        if (mode == 0) return launch_fast_L<L, 0, false, true>(p, cls, nitems, st);
+        return het ? launch_fast_L<L, 1, true, true>(p, cls, nitems, st) : launch_fast_L<L, 1, false, true>(p, cls, nitems, st);
+    }
+    if (mode == 0) return launch_fast_L<L, 0, false, false>(p, cls, nitems, st);
+    return het ? launch_fast_L<L, 1, true, false>(p, cls, nitems, st) : launch_fast_L<L, 1, false, false>(p, cls, nitems, st);
+}
+
+hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
+                             hipStream_t st)
+{
+    switch (L)
+    {
+#define CUSK_CASE(LL) \
+    case LL: return launch_fast_level<LL>(mode, het, validate, p, cls, nitems, st);
+        CUSK_CASE(2)
+        CUSK_CASE(3)
+        CUSK_CASE(4)
+        CUSK_CASE(5)
+        CUSK_CASE(6)
+        CUSK_CASE(7)
+        CUSK_CASE(8)
+        CUSK_CASE(9)
+        CUSK_CASE(10)
+        CUSK_CASE(11)
+        CUSK_CASE(12)
+        CUSK_CASE(13)
+        CUSK_CASE(14)
+#undef CUSK_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cusk

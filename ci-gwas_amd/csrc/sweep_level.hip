@@ -1,0 +1,594 @@
+// sweep_level.hip -- level 0, bitmap -> CSR compaction, the level-1 pair kernel and result expansion.
+//
+// Replaces /root/reference/cusk/src/cuPC-S.cu:458-484 (cal_Indepl0), :6355-6432 (scan_compact),
+// :486-582 (cal_Indepl1) and their hetcor twins (src/hetcor-cuPC-S.cu:343-486).
+#include "ci_exact.h"
+#include "sweep_common.h"
+
+namespace cusk {
+
+// ---------------------------------------------------------------------------
+// level 0
+// ---------------------------------------------------------------------------
+
+// adjacency bitmap <- complete graph without self loops (Skeleton) or the caller's G (hetcor)
+__global__ void init_bits_kernel(unsigned long long *adj, const int *Ginit, int n, int words)
+{
+    const int row = blockIdx.x;
+    for (int w = threadIdx.x; w < words; w += blockDim.x)
+    {
+        unsigned long long bits = 0;
+        const int base = w * 64;
+        if (Ginit == nullptr)
+        {
+            int valid = n - base;
+            bits = (valid >= 64) ? ~0ull : ((1ull << valid) - 1ull);
+        }
+        else
+        {
+            for (int b = 0; b < 64 && base + b < n; b++)
+                if (Ginit[(size_t)row * n + base + b] == 1) bits |= (1ull << b);
+        }
+        if (row >= base && row < base + 64) bits &= ~(1ull << (row - base));
+        adj[(size_t)row * words + w] = bits;
+    }
+}
+
+// One 64x64 tile of the upper triangle per workgroup (4 waves x 16 rows, lane = column):
+// coalesced 256-byte row segments in, wavefront ballots out (one 64-bit adjacency word per
+// tile row, plus the mirrored word through LDS).  The mirrored tile is loaded as well so that
+// level 0 also answers "is C bitwise symmetric?" (level 1 then reads only the upper triangle).
+template <bool ESS>
+__global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C, const float *__restrict__ N,
+                                                      unsigned long long *adj, int n, int words, float th, int tiles,
+                                                      int *asym_flag)
+{
+    __shared__ unsigned long long s_col[64];
+    __shared__ float s_t[64][65];
+    int t = blockIdx.x, bi = 0;
+    {
+        int rem = t, len = tiles;
+        while (rem >= len)
+        {
+            rem -= len;
+            len--;
+            bi++;
+        }
+        t = bi + rem;
+    }
+    const int bj = t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) s_col[threadIdx.x] = 0ull;
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int r = wave * 16 + rr;
+        const int jr = bj * 64 + r, ic = bi * 64 + lane;
+        s_t[r][lane] = (jr < n && ic < n) ? C[(size_t)jr * n + ic] : 0.0f;
+    }
+    __syncthreads();
+    const int j = bj * 64 + lane;
+    unsigned long long colbits = 0ull;
+    bool asym = false;
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int r = wave * 16 + rr;
+        const int i = bi * 64 + r;
+        bool rm = false;
+        if (i < n && j < n && i < j)
+        {
+            const float c = C[(size_t)i * n + j];
+            const float ct = s_t[lane][r];
+            asym |= (__float_as_uint(c) != __float_as_uint(ct)) && !((c != c) && (ct != ct));
+            float lth = th;
+            if constexpr (ESS) lth = (float)((double)th / sqrt((double)N[(size_t)i * n + j] - 3.0));
+            rm = z_below<false>(c, lth);
+        }
+        const unsigned long long m = __ballot(rm);
+        if (lane == 0 && m != 0ull) atomicAnd(&adj[(size_t)i * words + bj], ~m);
+        if (rm) colbits |= (1ull << r);
+    }
+    if (__ballot(asym) != 0ull && lane == 0) *asym_flag = 1;
+    if (colbits) atomicOr(&s_col[lane], colbits);
+    __syncthreads();
+    if (threadIdx.x < 64)
+    {
+        const unsigned long long m = s_col[threadIdx.x];
+        const int jj = bj * 64 + threadIdx.x;
+        if (m != 0ull && jj < n) atomicAnd(&adj[(size_t)jj * words + bi], ~m);
+    }
+}
+
+hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
+                         float th, int *asym_flag, hipStream_t st)
+{
+    hipLaunchKernelGGL(init_bits_kernel, dim3(n), dim3(64), 0, st, adj, Ginit, n, words);
+    const int tiles = words;
+    const long long ntile = (long long)tiles * (tiles + 1) / 2;
+    if (Ness)
+        hipLaunchKernelGGL(level0_kernel<true>, dim3((unsigned)ntile), dim3(256), 0, st, C, Ness, adj, n, words, th, tiles,
+                           asym_flag);
+    else
+        hipLaunchKernelGGL(level0_kernel<false>, dim3((unsigned)ntile), dim3(256), 0, st, C, Ness, adj, n, words, th, tiles,
+                           asym_flag);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// compaction: bitmap -> CSR neighbour lists + work list
+// ---------------------------------------------------------------------------
+
+__global__ void degree_kernel(const unsigned long long *__restrict__ adj, int *deg, int n, int words)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    int d = 0;
+    for (int w = lane; w < words; w += 64) d += __popcll(adj[(size_t)row * words + w]);
+    for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
+    if (lane == 0) deg[row] = d;
+}
+
+hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st)
+{
+    hipLaunchKernelGGL(degree_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, deg, n, words);
+    return hipGetLastError();
+}
+
+// single workgroup: off[0..n] = exclusive scan of deg, total and max degree to the level's counters
+__global__ void __launch_bounds__(1024) scan_degrees_kernel(const int *deg, int *off, int n, LevelCounters *cnt)
+{
+    __shared__ long long s_part[1024];
+    __shared__ int s_max[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    long long s = 0;
+    int mx = 0;
+    for (int i = lo; i < hi; i++)
+    {
+        const int d = deg[i];
+        s += d;
+        mx = max(mx, d);
+    }
+    s_part[threadIdx.x] = s;
+    s_max[threadIdx.x] = mx;
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1)
+    {
+        const long long v = (threadIdx.x >= step) ? s_part[threadIdx.x - step] : 0;
+        const int m2 = (threadIdx.x >= step) ? s_max[threadIdx.x - step] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        s_max[threadIdx.x] = max(s_max[threadIdx.x], m2);
+        __syncthreads();
+    }
+    long long run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
+    for (int i = lo; i < hi; i++)
+    {
+        off[i] = (int)run;
+        run += deg[i];
+    }
+    if (threadIdx.x == 1023)
+    {
+        off[n] = (int)s_part[1023];
+        cnt->total_edges = s_part[1023];
+        cnt->maxdeg = s_max[1023];
+    }
+}
+
+hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *cnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(scan_degrees_kernel, dim3(1), dim3(1024), 0, st, deg, off, n, cnt);
+    return hipGetLastError();
+}
+
+// one wave per row: ascending neighbour indices, reset of the row's selection state, work-item count
+__global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
+                                unsigned long long *best, int *rowfound, int n, int words, int L,
+                                const unsigned long long *__restrict__ binom, unsigned long long chunk,
+                                int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int o0 = off[row];
+    int run = 0;
+    for (int w0 = 0; w0 < words; w0 += 64)
+    {
+        const int w = w0 + lane;
+        unsigned long long bits = (w < words) ? adj[(size_t)row * words + w] : 0ull;
+        const int c = __popcll(bits);
+        int incl = c;
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const int v = __shfl_up(incl, o);
+            if (lane >= o) incl += v;
+        }
+        int pos = o0 + run + incl - c;
+        while (bits)
+        {
+            const int b = __ffsll((long long)bits) - 1;
+            bits &= bits - 1;
+            if (best) best[pos] = kNone;
+            nbr[pos++] = w * 64 + b;
+        }
+        run += __shfl(incl, 63);
+    }
+    if (lane == 0)
+    {
+        const int d = run;
+        RowInfo ri;
+        ri.cls = -1;
+        ri.base = 0;
+        ri.nchunks = 0;
+        ri.pad = 0;
+        if (rowfound) rowfound[row] = 0;
+        if (d > L)
+        {
+            // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
+            const unsigned long long nc =
+                pair_mode ? (unsigned long long)d * (d - 1) / 2 : binom[(size_t)d * kBinomStride + L];
+            if (nc >= (1ull << 62))
+                cnt->overflow = 1;
+            else
+            {
+                int cls = 0;
+                while (d > kClassCap[cls]) cls++;
+                if (cls >= staged_classes) cls = kNumClasses - 1;
+                ri.cls = cls;
+                ri.nchunks = (int)((nc + chunk - 1) / chunk);
+            }
+        }
+        rowinfo[row] = ri;
+    }
+}
+
+hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
+                           int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
+                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, L, binom,
+                       chunk, staged_classes, pair_mode, rowinfo, cnt);
+    return hipGetLastError();
+}
+
+// single workgroup: per-class exclusive scan of the rows' item counts -> RowInfo.base, class totals
+__global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
+{
+    __shared__ int s_part[kNumClasses][1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    int sum[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) sum[c] = 0;
+    for (int i = lo; i < hi; i++)
+    {
+        const RowInfo ri = rowinfo[i];
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++)
+            if (ri.cls == c) sum[c] += ri.nchunks;
+    }
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] = sum[c];
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1)
+    {
+        int v[kNumClasses];
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) v[c] = (threadIdx.x >= step) ? s_part[c][threadIdx.x - step] : 0;
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] += v[c];
+        __syncthreads();
+    }
+    int run[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++) run[c] = (threadIdx.x == 0) ? 0 : s_part[c][threadIdx.x - 1];
+    for (int i = lo; i < hi; i++)
+    {
+        RowInfo ri = rowinfo[i];
+        if (ri.cls >= 0)
+        {
+#pragma unroll
+            for (int c = 0; c < kNumClasses; c++)
+                if (ri.cls == c)
+                {
+                    ri.base = run[c];
+                    run[c] += ri.nchunks;
+                }
+            rowinfo[i] = ri;
+        }
+    }
+    if (threadIdx.x == 1023)
+    {
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++) cnt->class_items[c] = s_part[c][1023];
+    }
+}
+
+hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st)
+{
+    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, st, rowinfo, n, cnt);
+    return hipGetLastError();
+}
+
+struct ItemPtrs
+{
+    int2 *p[kNumClasses];
+};
+
+__global__ void fill_items_kernel(const RowInfo *__restrict__ rowinfo, int n, ItemPtrs ip)
+{
+    const int row = blockIdx.x;
+    const RowInfo ri = rowinfo[row];
+    if (ri.cls < 0) return;
+    int2 *dst = ip.p[ri.cls];
+    for (int c = threadIdx.x; c < ri.nchunks; c += blockDim.x) dst[ri.base + c] = make_int2(row, c);
+}
+
+hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st)
+{
+    ItemPtrs ip;
+    for (int c = 0; c < kNumClasses; c++) ip.p[c] = items[c];
+    hipLaunchKernelGGL(fill_items_kernel, dim3(n), dim3(64), 0, st, rowinfo, n, ip);
+    return hipGetLastError();
+}
+
+// single workgroup: recoff = exclusive scan of rowfound; level total; rec_base[level+1]
+__global__ void __launch_bounds__(1024) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
+                                                         long long *rec_base, int level)
+{
+    __shared__ int s_part[1024];
+    const int per = (n + 1023) / 1024;
+    const int lo = threadIdx.x * per, hi = min(n, lo + per);
+    int s = 0;
+    for (int i = lo; i < hi; i++) s += rowfound[i];
+    s_part[threadIdx.x] = s;
+    __syncthreads();
+    for (int step = 1; step < 1024; step <<= 1)
+    {
+        const int v = (threadIdx.x >= step) ? s_part[threadIdx.x - step] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
+    for (int i = lo; i < hi; i++)
+    {
+        recoff[i] = run;
+        run += rowfound[i];
+    }
+    if (threadIdx.x == 1023)
+    {
+        cnt->rec_total = (unsigned long long)s_part[1023];
+        rec_base[level + 1] = rec_base[level] + s_part[1023];
+    }
+}
+
+hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
+                           hipStream_t st)
+{
+    hipLaunchKernelGGL(rec_scan_kernel, dim3(1), dim3(1024), 0, st, rowfound, recoff, n, cnt, rec_base, level);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// level 1 on a symmetric matrix with a single threshold
+// ---------------------------------------------------------------------------
+// A level-1 test (X ; Y | S) needs C[X,Y], C[X,S] and C[Y,S]; the first two live in row X and
+// are staged once, the third is used by exactly two tests, (X;Y|S) and (X;S|Y), so staging a
+// (d+1)^2 sub-matrix buys no reuse.  Lane <-> unordered neighbour pair {a<b}: ONE 4-byte gather
+// of the upper-triangle element C[min,max] feeds both tests, pairs whose two tests are already
+// decided are skipped without touching memory, and with ~20 VGPRs the kernel runs at full
+// occupancy to hide the gather latency.  Arithmetic is the exact level-1 formula
+// (cuPC-S.cu:561-566), so nothing needs rechecking.
+template <int MODE>
+__global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[3];
+    const int2 item = p.items[blockIdx.x];
+    const int X = item.x;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    unsigned long long *s_best = reinterpret_cast<unsigned long long *>(smem);
+    int *s_nbr = reinterpret_cast<int *>(smem + sizeof(unsigned long long) * d);
+    float *s_m1x = reinterpret_cast<float *>(s_nbr + d);
+    int *s_ti = reinterpret_cast<int *>(s_m1x + d);
+    const int *g_nbr = p.nbr + o0;
+    if (tid < 3) s_cnt[tid] = 0ull;
+    for (int k = tid; k < d; k += kThreads)
+    {
+        const int y = g_nbr[k];
+        s_nbr[k] = y;
+        s_m1x[k] = p.C[(size_t)X * n + y];
+        if constexpr (MODE == 0)
+            s_best[k] = p.best[o0 + k];
+        else
+        {
+            const unsigned long long wv = p.adj[(size_t)X * p.words + (y >> 6)];
+            s_best[k] = ((wv >> (y & 63)) & 1ull) ? kNone : 0ull;
+            s_ti[k] = p.time_index[y];
+        }
+    }
+    __syncthreads();
+    [[maybe_unused]] int tiX = 0;
+    if constexpr (MODE == 1) tiX = p.time_index[X];
+
+    const unsigned long long npairs = (unsigned long long)d * (d - 1) / 2;
+    const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
+    const unsigned long long cntr = min(p.chunk, npairs - r0);
+    const unsigned long long q = (cntr + kThreads - 1) / kThreads;
+    const unsigned long long lo = r0 + (unsigned long long)tid * q;
+    const unsigned long long hi = min(r0 + cntr, lo + q);
+    unsigned long long ntests = 0, nrem = 0;
+    if (lo < hi)
+    {
+        // unrank the pair: row a of the strict upper triangle starts at a*d - a(a+1)/2
+        auto start_of = [&](int aa) -> unsigned long long {
+            return (unsigned long long)aa * d - (unsigned long long)aa * (aa + 1) / 2;
+        };
+        const double dd = (double)d - 0.5;
+        int a = (int)(dd - sqrt(fmax(dd * dd - 2.0 * (double)lo, 0.0)));
+        a = max(0, min(a, d - 2));
+        while (a > 0 && start_of(a) > lo) a--;
+        while (a < d - 2 && start_of(a + 1) <= lo) a++;
+        int b = a + 1 + (int)(lo - start_of(a));
+        auto apply = [&](int ky, int ks) {
+            // edge X - nbr[ky] is separated by S = nbr[ks]
+            if constexpr (MODE == 0)
+            {
+                const unsigned long long old = atomicMin(&p.best[o0 + ky], (unsigned long long)ks);
+                atomicMin(&s_best[ky], (unsigned long long)ks);
+                if (old == kNone)
+                {
+                    nrem++;
+                    atomicAdd(&p.rowfound[X], 1);
+                }
+            }
+            else
+            {
+                if (clear_edge(p.adj, p.deg, p.words, X, s_nbr[ky])) nrem++;
+                s_best[ky] = 0ull;
+            }
+        };
+        for (unsigned long long it = lo; it < hi; it++)
+        {
+            bool needA, needB;  // A: Y = a, S = b ; B: Y = b, S = a
+            if constexpr (MODE == 0)
+            {
+                needA = s_best[a] >= (unsigned long long)b;
+                needB = s_best[b] >= (unsigned long long)a;
+            }
+            else
+            {
+                needA = (s_best[a] == kNone) && !(s_ti[b] > max(tiX, s_ti[a]));
+                needB = (s_best[b] == kNone) && !(s_ti[a] > max(tiX, s_ti[b]));
+            }
+            if (needA || needB)
+            {
+                const int ya = s_nbr[a], yb = s_nbr[b];  // ascending lists: ya < yb
+                const float c = p.C[(size_t)ya * n + yb];
+                const float ra = s_m1x[a], rb = s_m1x[b];
+                const float hc = 1.0f - (c * c);
+                if (needA)
+                {
+                    const float H00 = 1.0f - (rb * rb);
+                    const float H01 = ra - (rb * c);
+                    const float rho = H01 / (sqrtf(fabsf(H00)) * sqrtf(fabsf(hc)));
+                    ntests++;
+                    if (z_below<true>(rho, p.th)) apply(a, b);
+                }
+                if (needB)
+                {
+                    const float H00 = 1.0f - (ra * ra);
+                    const float H01 = rb - (ra * c);
+                    const float rho = H01 / (sqrtf(fabsf(H00)) * sqrtf(fabsf(hc)));
+                    ntests++;
+                    if (z_below<true>(rho, p.th)) apply(b, a);
+                }
+            }
+            b++;
+            if (b == d)
+            {
+                a++;
+                b = a + 1;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);
+        nrem += __shfl_xor(nrem, o);
+    }
+    if ((tid & 63) == 0)
+    {
+        atomicAdd(&s_cnt[0], ntests);
+        atomicAdd(&s_cnt[2], nrem);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
+    }
+}
+
+hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st)
+{
+    if (nitems <= 0) return hipSuccess;
+    if (mode == 0)
+        hipLaunchKernelGGL(level1_pair_kernel<0>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    else
+        hipLaunchKernelGGL(level1_pair_kernel<1>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// result expansion into the reference's dense layouts
+// ---------------------------------------------------------------------------
+
+__global__ void expand_adj_kernel(const unsigned long long *__restrict__ adj, int *G, int n, int words)
+{
+    const int row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    const unsigned long long w = adj[(size_t)row * words + (col >> 6)];
+    G[(size_t)row * n + col] = (int)((w >> (col & 63)) & 1ull);
+}
+
+hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st)
+{
+    hipLaunchKernelGGL(expand_adj_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, adj, G, n, words);
+    return hipGetLastError();
+}
+
+// pMax before the sparse records are applied (cuPC-S.cu:424-442 semantics): -100000 on
+// surviving edges, 1 on the diagonal, level-0 z where level 0 removed the pair, else 0.
+__global__ void expand_pmax_kernel(const unsigned long long *__restrict__ adj,
+                                   const unsigned long long *__restrict__ adj0, const float *__restrict__ C,
+                                   float *pmax, int n, int words)
+{
+    const int row = blockIdx.y;
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n) return;
+    const bool live = (adj[(size_t)row * words + (col >> 6)] >> (col & 63)) & 1ull;
+    const bool live0 = (adj0[(size_t)row * words + (col >> 6)] >> (col & 63)) & 1ull;
+    float v;
+    if (row == col)
+        v = 1.0f;
+    else if (live)
+        v = -100000.0f;
+    else if (!live0)
+    {
+        const int i = min(row, col), j = max(row, col);
+        v = fisher_z_ratio(C[(size_t)i * n + j]);
+    }
+    else
+        v = 0.0f;
+    pmax[(size_t)row * n + col] = v;
+}
+
+__global__ void scatter_pmax_kernel(const int *x, const int *y, const float *z, long long nrec, float *pmax, int n)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nrec) return;
+    // a stored z is never NaN (NaN fails z < th) and never negative: integer order == float order
+    const int zi = __float_as_int(z[i]);
+    atomicMax(reinterpret_cast<int *>(&pmax[(size_t)x[i] * n + y[i]]), zi);
+    atomicMax(reinterpret_cast<int *>(&pmax[(size_t)y[i] * n + x[i]]), zi);
+}
+
+hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,
+                              int n, int words, const int *x, const int *y, const float *z, long long nrec, hipStream_t st)
+{
+    hipLaunchKernelGGL(expand_pmax_kernel, dim3((n + 255) / 256, n), dim3(256), 0, st, adj, adj0, C, pmax, n, words);
+    if (nrec > 0)
+        hipLaunchKernelGGL(scatter_pmax_kernel, dim3((unsigned)((nrec + 255) / 256)), dim3(256), 0, st, x, y, z, nrec, pmax,
+                           n);
+    return hipGetLastError();
+}
+
+}  // namespace cusk
