@@ -79,6 +79,7 @@ struct cusk_engine
     long long *hrec_base = nullptr;        // kLevels + 1
     int *hflag = nullptr;
     std::vector<unsigned long long> binom_host;
+    long long binom_rows = 0;  // rows of the device-resident binomial table
     hipEvent_t ev_run[2] = {nullptr, nullptr};
     hipEvent_t ev_k0[cusk::kLevels], ev_k1[cusk::kLevels], ev_l0[cusk::kLevels], ev_l1[cusk::kLevels];
 
@@ -86,6 +87,7 @@ struct cusk_engine
     int opt_fast = 1;
     int opt_validate = 0;
     int opt_pair = 1;
+    int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
 

@@ -134,7 +134,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         float th0 = a.Th[0];
         if (a.mode == 1 && !het) th0 = (float)((double)a.Th[0] / std::sqrt((double)a.ess_uniform - 3.0));
         CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
-                                  e->symflag.as<int>(), s));
+                                  e->opt_assume_symmetric ? nullptr : e->symflag.as<int>(), s));
         if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
     }
     CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
@@ -209,7 +209,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 CUSK_HIP(e, hipMemcpyAsync(e->hflag, e->symflag.p, sizeof(int), hipMemcpyDeviceToHost, s));
                 int rc = sync_counters();
                 if (rc != CUSK_OK) return rc;
-                symmetric = (*e->hflag == 0);
+                symmetric = (*e->hflag == 0) || (e->opt_assume_symmetric != 0);
                 cap_edges = std::max<long long>(e->hcnt[1].total_edges, 1);
                 const int maxdeg1 = e->hcnt[1].maxdeg;
                 for (int k = 0; k < 2; k++)
@@ -225,12 +225,21 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     CUSK_HIP(e, e->rec_z.ensure(sizeof(float) * (size_t)cap_edges));
                     CUSK_HIP(e, e->rec_s.ensure(sizeof(int) * kML * (size_t)cap_edges));
                 }
-                e->binom_host.assign((size_t)(maxdeg1 + 1) * kBinomStride, 0ull);
-                for (int aa = 0; aa <= maxdeg1; aa++)
-                    for (int b = 0; b < kBinomStride; b++) e->binom_host[(size_t)aa * kBinomStride + b] = binom_sat(aa, b);
-                CUSK_HIP(e, e->binom.ensure(e->binom_host.size() * sizeof(unsigned long long)));
-                CUSK_HIP(e, hipMemcpyAsync(e->binom.p, e->binom_host.data(),
-                                           e->binom_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+                if (a.mode == 0)
+                    CUSK_HIP(e, hipMemsetAsync(e->rec_s.p, 0xFF, sizeof(int) * kML * (size_t)cap_edges, s));
+                // binomial table C(a, b), a <= max degree: kept on the device across runs
+                if ((long long)maxdeg1 >= e->binom_rows)
+                {
+                    const int rows = std::max(maxdeg1 + 1, 1024);
+                    e->binom_host.assign((size_t)rows * kBinomStride, 0ull);
+                    for (int aa = 0; aa < rows; aa++)
+                        for (int b = 0; b < kBinomStride; b++)
+                            e->binom_host[(size_t)aa * kBinomStride + b] = binom_sat(aa, b);
+                    CUSK_HIP(e, e->binom.ensure(e->binom_host.size() * sizeof(unsigned long long)));
+                    CUSK_HIP(e, hipMemcpyAsync(e->binom.p, e->binom_host.data(),
+                                               e->binom_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
+                    e->binom_rows = rows;
+                }
             }
             // which classes can be staged in LDS in this mode
             int staged_classes = 0;
@@ -487,6 +496,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_validate = (int)value;
     else if (k == "pair")
         e->opt_pair = (int)value;
+    else if (k == "assume_symmetric")
+        e->opt_assume_symmetric = (int)value;
     else if (k == "queue_capacity" && value > 0)
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)

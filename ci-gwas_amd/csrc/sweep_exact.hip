@@ -219,21 +219,22 @@ hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipSt
 }
 
 // ---------------------------------------------------------------------------
-// Skeleton mode: selected ranks -> sparse separating-set records.  One wave per row; the
-// record index is rec_base[level] + recoff[row] + (number of earlier selected slots of the
-// row), so records are ordered by (level, X, position of Y) without any atomics.  The winner's
-// Fisher z is recomputed on the exact path (pMax does not depend on which lane found it) and
-// the edge is cleared in both directions.
+// Skeleton mode: selected ranks -> sparse separating-set records, in two steps.
+//  gather_records_kernel (one wave per row, no heavy arithmetic): the record index is
+//    rec_base[level] + recoff[row] + (number of earlier selected slots of the row), so records
+//    are ordered by (level, X, position of Y) without atomics; writes x, y, level and the L
+//    members of S (rec_s is pre-filled with -1) and clears the edge in both directions.
+//  record_z_kernel<L> (one lane per record of this level, count read on the device): the
+//    winner's Fisher z recomputed on the exact path, so pMax never depends on which lane won.
 // ---------------------------------------------------------------------------
 template <int L>
-__global__ void finalize_kernel(FinalizeParams p)
+__global__ void gather_records_kernel(FinalizeParams p)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= p.n) return;
     const int o0 = p.off[row];
     const int d = p.off[row + 1] - o0;
-    const int n = p.n;
     long long next = p.rec_base[p.level] + p.recoff[row];
     for (int k0 = 0; k0 < d; k0 += 64)
     {
@@ -246,10 +247,28 @@ __global__ void finalize_kernel(FinalizeParams p)
         if (r == kNone) continue;
         int idx[L];
         unrank_comb<L>(r, d, p.binom, idx);
-        const int X = row, Y = p.nbr[o0 + k];
+        const int Y = p.nbr[o0 + k];
+        p.rec_x[slot] = row;
+        p.rec_y[slot] = Y;
+        p.rec_l[slot] = L;
+#pragma unroll
+        for (int a = 0; a < L; a++) p.rec_s[slot * kML + a] = p.nbr[o0 + idx[a]];
+        (void)clear_edge(p.adj, p.deg, p.words, row, Y);
+    }
+}
+
+template <int L>
+__global__ void __launch_bounds__(256) record_z_kernel(FinalizeParams p)
+{
+    const long long first = p.rec_base[p.level], count = p.rec_base[p.level + 1] - first;
+    const int n = p.n;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
+    {
+        const long long slot = first + i;
+        const int X = p.rec_x[slot], Y = p.rec_y[slot];
         int S[L];
 #pragma unroll
-        for (int a = 0; a < L; a++) S[a] = p.nbr[o0 + idx[a]];
+        for (int a = 0; a < L; a++) S[a] = p.rec_s[slot * kML + a];
         float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
 #pragma unroll
         for (int a = 0; a < L; a++)
@@ -271,24 +290,21 @@ __global__ void finalize_kernel(FinalizeParams p)
         const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
         float z;
         (void)z_below<L == 1>(rho, 0.0f, &z);
-        p.rec_x[slot] = X;
-        p.rec_y[slot] = Y;
-        p.rec_l[slot] = L;
         p.rec_z[slot] = z;
-#pragma unroll
-        for (int a = 0; a < kML; a++) p.rec_s[slot * kML + a] = (a < L) ? S[a < L ? a : 0] : -1;
-        (void)clear_edge(p.adj, p.deg, p.words, X, Y);
     }
 }
 
 hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
 {
     const dim3 grid((p.n + 3) / 4), block(256);
+    // level 1 produces ~1e6 records on a 10k block, deeper levels a handful
+    const dim3 zgrid(L == 1 ? 2048 : 64);
     switch (L)
     {
-#define CUSK_CASE(LL)                                                   \
-    case LL:                                                            \
-        hipLaunchKernelGGL(finalize_kernel<LL>, grid, block, 0, st, p); \
+#define CUSK_CASE(LL)                                                          \
+    case LL:                                                                   \
+        hipLaunchKernelGGL(gather_records_kernel<LL>, grid, block, 0, st, p);  \
+        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, block, 0, st, p);       \
         break;
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE

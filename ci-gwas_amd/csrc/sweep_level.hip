@@ -38,7 +38,7 @@ __global__ void init_bits_kernel(unsigned long long *adj, const int *Ginit, int 
 // coalesced 256-byte row segments in, wavefront ballots out (one 64-bit adjacency word per
 // tile row, plus the mirrored word through LDS).  The mirrored tile is loaded as well so that
 // level 0 also answers "is C bitwise symmetric?" (level 1 then reads only the upper triangle).
-template <bool ESS>
+template <bool ESS, bool SYMCHECK>
 __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C, const float *__restrict__ N,
                                                       unsigned long long *adj, int n, int words, float th, int tiles,
                                                       int *asym_flag)
@@ -59,11 +59,14 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
     const int bj = t;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x < 64) s_col[threadIdx.x] = 0ull;
-    for (int rr = 0; rr < 16; rr++)
+    if constexpr (SYMCHECK)
     {
-        const int r = wave * 16 + rr;
-        const int jr = bj * 64 + r, ic = bi * 64 + lane;
-        s_t[r][lane] = (jr < n && ic < n) ? C[(size_t)jr * n + ic] : 0.0f;
+        for (int rr = 0; rr < 16; rr++)
+        {
+            const int r = wave * 16 + rr;
+            const int jr = bj * 64 + r, ic = bi * 64 + lane;
+            s_t[r][lane] = (jr < n && ic < n) ? C[(size_t)jr * n + ic] : 0.0f;
+        }
     }
     __syncthreads();
     const int j = bj * 64 + lane;
@@ -77,8 +80,11 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
         if (i < n && j < n && i < j)
         {
             const float c = C[(size_t)i * n + j];
-            const float ct = s_t[lane][r];
-            asym |= (__float_as_uint(c) != __float_as_uint(ct)) && !((c != c) && (ct != ct));
+            if constexpr (SYMCHECK)
+            {
+                const float ct = s_t[lane][r];
+                asym |= (__float_as_uint(c) != __float_as_uint(ct)) && !((c != c) && (ct != ct));
+            }
             float lth = th;
             if constexpr (ESS) lth = (float)((double)th / sqrt((double)N[(size_t)i * n + j] - 3.0));
             rm = z_below<false>(c, lth);
@@ -87,7 +93,10 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
         if (lane == 0 && m != 0ull) atomicAnd(&adj[(size_t)i * words + bj], ~m);
         if (rm) colbits |= (1ull << r);
     }
-    if (__ballot(asym) != 0ull && lane == 0) *asym_flag = 1;
+    if constexpr (SYMCHECK)
+    {
+        if (__ballot(asym) != 0ull && lane == 0) *asym_flag = 1;
+    }
     if (colbits) atomicOr(&s_col[lane], colbits);
     __syncthreads();
     if (threadIdx.x < 64)
@@ -104,12 +113,15 @@ hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, un
     hipLaunchKernelGGL(init_bits_kernel, dim3(n), dim3(64), 0, st, adj, Ginit, n, words);
     const int tiles = words;
     const long long ntile = (long long)tiles * (tiles + 1) / 2;
-    if (Ness)
-        hipLaunchKernelGGL(level0_kernel<true>, dim3((unsigned)ntile), dim3(256), 0, st, C, Ness, adj, n, words, th, tiles,
-                           asym_flag);
+    const dim3 grid((unsigned)ntile), block(256);
+    if (Ness && asym_flag)
+        hipLaunchKernelGGL((level0_kernel<true, true>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
+    else if (Ness)
+        hipLaunchKernelGGL((level0_kernel<true, false>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
+    else if (asym_flag)
+        hipLaunchKernelGGL((level0_kernel<false, true>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
     else
-        hipLaunchKernelGGL(level0_kernel<false>, dim3((unsigned)ntile), dim3(256), 0, st, C, Ness, adj, n, words, th, tiles,
-                           asym_flag);
+        hipLaunchKernelGGL((level0_kernel<false, false>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
     return hipGetLastError();
 }
 
@@ -251,10 +263,27 @@ hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *n
     return hipGetLastError();
 }
 
+// inclusive scan of one value per thread across a 1024-thread workgroup (16 waves): wave shuffles + one LDS hop
+__device__ __forceinline__ int block_scan_incl_1024(int v, int *s_wave /* 16 ints */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const int t = __shfl_up(v, o);
+        if (lane >= o) v += t;
+    }
+    if (lane == 63) s_wave[wave] = v;
+    __syncthreads();
+    int add = 0;
+    for (int w = 0; w < wave; w++) add += s_wave[w];
+    __syncthreads();
+    return v + add;
+}
+
 // single workgroup: per-class exclusive scan of the rows' item counts -> RowInfo.base, class totals
 __global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
 {
-    __shared__ int s_part[kNumClasses][1024];
+    __shared__ int s_wave[16];
     const int per = (n + 1023) / 1024;
     const int lo = threadIdx.x * per, hi = min(n, lo + per);
     int sum[kNumClasses];
@@ -267,22 +296,14 @@ __global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n
         for (int c = 0; c < kNumClasses; c++)
             if (ri.cls == c) sum[c] += ri.nchunks;
     }
-#pragma unroll
-    for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] = sum[c];
-    __syncthreads();
-    for (int step = 1; step < 1024; step <<= 1)
-    {
-        int v[kNumClasses];
-#pragma unroll
-        for (int c = 0; c < kNumClasses; c++) v[c] = (threadIdx.x >= step) ? s_part[c][threadIdx.x - step] : 0;
-        __syncthreads();
-#pragma unroll
-        for (int c = 0; c < kNumClasses; c++) s_part[c][threadIdx.x] += v[c];
-        __syncthreads();
-    }
     int run[kNumClasses];
 #pragma unroll
-    for (int c = 0; c < kNumClasses; c++) run[c] = (threadIdx.x == 0) ? 0 : s_part[c][threadIdx.x - 1];
+    for (int c = 0; c < kNumClasses; c++)
+    {
+        const int incl = block_scan_incl_1024(sum[c], s_wave);
+        run[c] = incl - sum[c];
+        if (threadIdx.x == 1023) cnt->class_items[c] = incl;
+    }
     for (int i = lo; i < hi; i++)
     {
         RowInfo ri = rowinfo[i];
@@ -297,11 +318,6 @@ __global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n
                 }
             rowinfo[i] = ri;
         }
-    }
-    if (threadIdx.x == 1023)
-    {
-#pragma unroll
-        for (int c = 0; c < kNumClasses; c++) cnt->class_items[c] = s_part[c][1023];
     }
 }
 
