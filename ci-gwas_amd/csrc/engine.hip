@@ -253,6 +253,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             pl.pair_lds = (size_t)maxdeg_bound * 20 + 16;
             pl.use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
             pl.use_fast = (e->opt_fast != 0) && (l >= 2);
+            if (rebuilt)  // item_scan accumulates the class totals with atomics: start from zero again
+                CUSK_HIP(e, hipMemsetAsync(&dcnt[l].class_items[0], 0, sizeof(long long) * kNumClasses, s));
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
                                         a.mode == 0 ? e->best[cs].as<unsigned long long>() : nullptr,
                                         a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,

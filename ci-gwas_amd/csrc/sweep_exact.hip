@@ -199,7 +199,8 @@ __global__ void __launch_bounds__(256) recheck_kernel(SweepParams p)
 
 hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st)
 {
-    const dim3 grid(512), block(256);
+    // level 2 queues ~1e3 tests on a 10k block, deeper levels tens: a small grid-stride launch
+    const dim3 grid(L <= 3 ? 128 : 32), block(256);
     switch (L)
     {
 #define CUSK_CASE(LL)                                                                             \
@@ -236,10 +237,33 @@ __global__ void gather_records_kernel(FinalizeParams p)
     const int o0 = p.off[row];
     const int d = p.off[row + 1] - o0;
     long long next = p.rec_base[p.level] + p.recoff[row];
+    int removed = 0;
     for (int k0 = 0; k0 < d; k0 += 64)
     {
         const int k = k0 + lane;
-        const unsigned long long r = (k < d) ? p.best[o0 + k] : kNone;
+        const bool valid = k < d;
+        const unsigned long long r = valid ? p.best[o0 + k] : kNone;
+        const int Y = valid ? p.nbr[o0 + k] : 0;
+        // The edge row - Y goes when EITHER side found a separating set.  Every wave only ever
+        // touches its own row of the bitmap and its own degree, so no returning atomics are needed:
+        // the other side's verdict is looked up (position of `row` in Y's ascending list).
+        bool gone = (r != kNone);
+        if (valid && !gone)
+        {
+            const int oy = p.off[Y];
+            int lo = 0, hi = p.off[Y + 1] - oy;
+            while (lo < hi)
+            {
+                const int mid = (lo + hi) >> 1;
+                if (p.nbr[oy + mid] < row)
+                    lo = mid + 1;
+                else
+                    hi = mid;
+            }
+            gone = (p.best[oy + lo] != kNone);  // adjacency is symmetric at level start: nbr[oy+lo] == row
+        }
+        if (gone) atomicAnd(&p.adj[(size_t)row * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
+        removed += __popcll(__ballot(gone));
         const unsigned long long has = __ballot(r != kNone);
         if (has == 0ull) continue;
         const long long slot = next + __popcll(has & ((1ull << lane) - 1ull));
@@ -247,14 +271,13 @@ __global__ void gather_records_kernel(FinalizeParams p)
         if (r == kNone) continue;
         int idx[L];
         unrank_comb<L>(r, d, p.binom, idx);
-        const int Y = p.nbr[o0 + k];
         p.rec_x[slot] = row;
         p.rec_y[slot] = Y;
         p.rec_l[slot] = L;
 #pragma unroll
         for (int a = 0; a < L; a++) p.rec_s[slot * kML + a] = p.nbr[o0 + idx[a]];
-        (void)clear_edge(p.adj, p.deg, p.words, row, Y);
     }
+    if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
 }
 
 template <int L>

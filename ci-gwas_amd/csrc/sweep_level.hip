@@ -263,67 +263,58 @@ hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *n
     return hipGetLastError();
 }
 
-// inclusive scan of one value per thread across a 1024-thread workgroup (16 waves): wave shuffles + one LDS hop
-__device__ __forceinline__ int block_scan_incl_1024(int v, int *s_wave /* 16 ints */)
+// Places every row's work items inside its class list.  256 rows per workgroup: block-level
+// exclusive scans of the rows' item counts (one per class), then one atomicAdd per class and
+// workgroup reserves the block's range (order between workgroups is irrelevant: items of a class
+// are independent).  class_items[] ends up holding the class totals.
+__global__ void __launch_bounds__(256) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
 {
+    __shared__ int s_wave[kNumClasses][4];
+    __shared__ long long s_base[kNumClasses];
+    const int row = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int o = 1; o < 64; o <<= 1)
-    {
-        const int t = __shfl_up(v, o);
-        if (lane >= o) v += t;
-    }
-    if (lane == 63) s_wave[wave] = v;
-    __syncthreads();
-    int add = 0;
-    for (int w = 0; w < wave; w++) add += s_wave[w];
-    __syncthreads();
-    return v + add;
-}
-
-// single workgroup: per-class exclusive scan of the rows' item counts -> RowInfo.base, class totals
-__global__ void __launch_bounds__(1024) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
-{
-    __shared__ int s_wave[16];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
-    int sum[kNumClasses];
-#pragma unroll
-    for (int c = 0; c < kNumClasses; c++) sum[c] = 0;
-    for (int i = lo; i < hi; i++)
-    {
-        const RowInfo ri = rowinfo[i];
-#pragma unroll
-        for (int c = 0; c < kNumClasses; c++)
-            if (ri.cls == c) sum[c] += ri.nchunks;
-    }
-    int run[kNumClasses];
+    RowInfo ri;
+    ri.cls = -1;
+    ri.nchunks = 0;
+    if (row < n) ri = rowinfo[row];
+    int excl[kNumClasses];
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
     {
-        const int incl = block_scan_incl_1024(sum[c], s_wave);
-        run[c] = incl - sum[c];
-        if (threadIdx.x == 1023) cnt->class_items[c] = incl;
-    }
-    for (int i = lo; i < hi; i++)
-    {
-        RowInfo ri = rowinfo[i];
-        if (ri.cls >= 0)
+        const int mine = (ri.cls == c) ? ri.nchunks : 0;
+        int v = mine;
+        for (int o = 1; o < 64; o <<= 1)
         {
-#pragma unroll
-            for (int c = 0; c < kNumClasses; c++)
-                if (ri.cls == c)
-                {
-                    ri.base = run[c];
-                    run[c] += ri.nchunks;
-                }
-            rowinfo[i] = ri;
+            const int t = __shfl_up(v, o);
+            if (lane >= o) v += t;
         }
+        excl[c] = v - mine;
+        if (lane == 63) s_wave[c][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumClasses)
+    {
+        const int c = threadIdx.x;
+        const int tot = s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
+        s_base[c] = tot ? (long long)atomicAdd((unsigned long long *)&cnt->class_items[c], (unsigned long long)tot) : 0;
+    }
+    __syncthreads();
+    if (row < n && ri.cls >= 0)
+    {
+        int add = 0;
+        for (int w = 0; w < wave; w++) add += s_wave[ri.cls][w];
+        int e = 0;
+#pragma unroll
+        for (int c = 0; c < kNumClasses; c++)
+            if (ri.cls == c) e = excl[c];
+        ri.base = (int)s_base[ri.cls] + add + e;
+        rowinfo[row] = ri;
     }
 }
 
 hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st)
 {
-    hipLaunchKernelGGL(item_scan_kernel, dim3(1), dim3(1024), 0, st, rowinfo, n, cnt);
+    hipLaunchKernelGGL(item_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowinfo, n, cnt);
     return hipGetLastError();
 }
 
