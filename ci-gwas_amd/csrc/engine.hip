@@ -159,6 +159,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.cap = kClassCap[c];
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, s));
+            else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
+                     sweep_vec_lds_bytes(c) <= kLdsLimit)
+                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, pl.nitems[c], s));
             else if (pl.use_fast && !exact_only)
                 CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], s));
             else
@@ -498,6 +501,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_validate = (int)value;
     else if (k == "pair")
         e->opt_pair = (int)value;
+    else if (k == "vec")
+        e->opt_vec = (int)value;
     else if (k == "assume_symmetric")
         e->opt_assume_symmetric = (int)value;
     else if (k == "queue_capacity" && value > 0)

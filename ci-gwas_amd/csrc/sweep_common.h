@@ -142,6 +142,9 @@ hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st);
 // sweep_fast.hip
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
                              hipStream_t st);
+// sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st);
+size_t sweep_vec_lds_bytes(int cls);
 // sweep_level.hip: level 0, compaction, level-1 pair kernel, result expansion
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st);

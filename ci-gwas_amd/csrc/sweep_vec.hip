@@ -1,0 +1,333 @@
+// sweep_vec.hip -- the flagship level-sweep kernel: levels >= 2, single threshold per level
+// (Skeleton, or hetcor with a uniform effective sample size), rows whose sub-matrix fits LDS.
+//
+// Same algorithm and certification rule as sweep_fast_kernel (register Cholesky per
+// conditioning set, one forward substitution per test, guard-band filter, uncertain tests
+// queued for the exact path), restructured around the CDNA4 issue model:
+//   * the (d+1)^2 sub-matrix is staged TRANSPOSED with a leading dimension ld4 = 4 (mod 8):
+//     the l operands C[Y, S_a] of four consecutive Y are 16 contiguous bytes, so one
+//     ds_read_b128 per conditioning variable feeds four tests, and consecutive conditioning
+//     columns land on distinct 16-byte slots of the 256-byte bank row (conflict-free);
+//   * the Y loop runs in groups of four with all four tests evaluated branch-free as float2
+//     pairs (v_pk_fma_f32 / v_pk_mul_f32); liveness, membership of S and the verdicts are
+//     bit masks, and only the rare "separated" / "uncertain" lanes leave the straight line;
+//   * selection state is kept chunk-relative in 32 bits (0 = decided below this chunk,
+//     0xffffffff = undecided), so four states are one ds_read_b128 as well.
+// Roughly 25 issued instructions per test at l = 5 instead of ~100.
+#include "ci_fast.h"
+#include "sweep_common.h"
+
+namespace cusk {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int vec_ld4(int d)
+{
+    int ld = (d + 1 + 3) & ~3;
+    if ((ld & 7) == 0) ld += 4;
+    return ld;
+}
+
+struct VecLayout
+{
+    size_t rel, rowx, nbr, ti, sub, total;
+};
+__host__ __device__ inline VecLayout vec_layout(int cap)
+{
+    VecLayout l;
+    const size_t dp = (size_t)((cap + 4) & ~3);  // d rounded up to a multiple of 4 (+ room)
+    l.rel = 0;
+    l.rowx = align16(l.rel + sizeof(unsigned) * dp);
+    l.nbr = align16(l.rowx + sizeof(float) * dp);
+    l.ti = align16(l.nbr + sizeof(int) * (cap + 1));
+    l.sub = align16(l.ti + sizeof(int) * (cap + 1));
+    l.total = align16(l.sub + sizeof(float) * (size_t)(cap + 1) * vec_ld4(cap));
+    return l;
+}
+
+template <int L, int MODE>
+__global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
+{
+    static_assert(L >= 2, "level 1 has its own kernels");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[4];
+
+    const int2 item = p.items[blockIdx.x];
+    const int X = item.x;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    const int ld4 = vec_ld4(d);
+    const int dp = (d + 3) & ~3;
+    const int *g_nbr = p.nbr + o0;
+
+    const VecLayout lay = vec_layout(p.cap);
+    unsigned *s_rel = reinterpret_cast<unsigned *>(smem + lay.rel);
+    float *s_rowx = reinterpret_cast<float *>(smem + lay.rowx);
+    int *s_nbr = reinterpret_cast<int *>(smem + lay.nbr);
+    int *s_ti = reinterpret_cast<int *>(smem + lay.ti);
+    float *s_sub = reinterpret_cast<float *>(smem + lay.sub);
+
+    const unsigned long long ncomb = p.binom[(size_t)d * kBinomStride + L];
+    const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
+    const unsigned long long cntr = min(p.chunk, ncomb - r0);
+
+    if (tid < 4) s_cnt[tid] = 0ull;
+    for (int k = tid; k <= d; k += kThreads)
+    {
+        const int v = (k < d) ? g_nbr[k] : X;
+        s_nbr[k] = v;
+        if constexpr (MODE == 1) s_ti[k] = p.time_index[v];
+    }
+    for (int k = tid; k < dp; k += kThreads)
+    {
+        unsigned rel = 0u;  // padding entries are "decided"
+        float rx = 0.0f;
+        if (k < d)
+        {
+            const int y = g_nbr[k];
+            rx = p.C[(size_t)X * n + y];
+            if constexpr (MODE == 0)
+            {
+                // 0 = decided below this chunk; otherwise (lowest passing rank - r0 + 1), saturated
+                const unsigned long long b = p.best[o0 + k];
+                rel = (b == kNone) ? 0xffffffffu : ((b < r0) ? 0u : (unsigned)min(b - r0 + 1ull, 0xfffffffeull));
+            }
+            else
+            {
+                const unsigned long long wv = p.adj[(size_t)X * p.words + (y >> 6)];
+                rel = ((wv >> (y & 63)) & 1ull) ? 0xffffffffu : 0u;
+            }
+        }
+        s_rel[k] = rel;
+        s_rowx[k] = rx;
+    }
+    __syncthreads();
+    {
+        // element (row i, col j) of C[adj(X)]^2 at s_sub[j * ld4 + i]; rows/cols 0..d-1 (X itself is s_rowx)
+        for (int e = tid; e < d * dp; e += kThreads)
+        {
+            const int j = e / dp, i = e - j * dp;
+            s_sub[j * ld4 + i] = (i < d) ? p.C[(size_t)s_nbr[i] * n + s_nbr[j]] : 0.0f;
+        }
+    }
+    __syncthreads();
+
+    const unsigned long long q = (cntr + kThreads - 1) / kThreads;
+    const unsigned long long lo = r0 + (unsigned long long)tid * q;
+    const unsigned long long hi = min(r0 + cntr, lo + q);
+    const float t2lo = p.t2 * (1.0f - kBeta), t2hi = p.t2 * (1.0f + kBeta);
+    [[maybe_unused]] const int tiX = (MODE == 1) ? s_ti[d] : 0;
+
+    unsigned long long ntests = 0, nsub = 0, nrem = 0;
+    if (lo < hi)
+    {
+        int idx[L];
+        unrank_comb<L>(lo, d, p.binom, idx);
+        for (unsigned long long rank = lo; rank < hi; rank++)
+        {
+            const unsigned myrel = (unsigned)(rank - r0) + 1u;  // >= 1: padding and decided entries (0) are never live
+            SubsetFast<L> fx;
+            {
+                float cl[SubsetFast<L>::NL], m1x[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) m1x[a] = s_rowx[idx[a]];
+#pragma unroll
+                for (int a = 1; a < L; a++)
+#pragma unroll
+                    for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = s_sub[idx[a] * ld4 + idx[b]];  // C[S_b, S_a]
+                fx.prepare(cl, m1x);
+            }
+            nsub++;
+            [[maybe_unused]] int tmaxS = 0;
+            if constexpr (MODE == 1)
+            {
+                tmaxS = s_ti[idx[0]];
+#pragma unroll
+                for (int a = 1; a < L; a++) tmaxS = max(tmaxS, s_ti[idx[a]]);
+            }
+            const float *col[L];
+#pragma unroll
+            for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
+            const f2 h00v = {fx.h00, fx.h00};
+            bool anyalive = false;
+            for (int g = 0; g < dp; g += 4)
+            {
+                const u4 rel = *reinterpret_cast<const u4 *>(s_rel + g);
+                unsigned livem = (rel.x >= myrel ? 1u : 0u) | (rel.y >= myrel ? 2u : 0u) | (rel.z >= myrel ? 4u : 0u) |
+                                 (rel.w >= myrel ? 8u : 0u);
+                anyalive |= (livem != 0u);
+                // members of S inside this group of four are not tested
+#pragma unroll
+                for (int a = 0; a < L; a++)
+                    if ((idx[a] >> 2) == (g >> 2)) livem &= ~(1u << (idx[a] & 3));
+                if constexpr (MODE == 1)
+                {
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (tmaxS > max(tiX, s_ti[min(g + u, d)])) livem &= ~(1u << u);
+                }
+                if (livem == 0u) continue;
+                // four tests, evaluated as two float2 pairs
+                f4 my[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) my[a] = *reinterpret_cast<const f4 *>(col[a] + g);
+                const f4 m0 = *reinterpret_cast<const f4 *>(s_rowx + g);
+                f2 bA[L], bB[L];
+                f2 h11A = {1.0f, 1.0f}, h11B = {1.0f, 1.0f};
+                f2 h01A = {m0.x, m0.y}, h01B = {m0.z, m0.w};
+#pragma unroll
+                for (int i = 0; i < L; i++)
+                {
+                    f2 sA = {my[i].x, my[i].y}, sB = {my[i].z, my[i].w};
+#pragma unroll
+                    for (int k = 0; k < i; k++)
+                    {
+                        const float fik = fx.f[i * (i - 1) / 2 + k];
+                        const f2 nf = {-fik, -fik};
+                        sA = __builtin_elementwise_fma(nf, bA[k], sA);
+                        sB = __builtin_elementwise_fma(nf, bB[k], sB);
+                    }
+                    const f2 iv = {fx.invd[i], fx.invd[i]};
+                    bA[i] = sA * iv;
+                    bB[i] = sB * iv;
+                    h11A = __builtin_elementwise_fma(-bA[i], bA[i], h11A);
+                    h11B = __builtin_elementwise_fma(-bB[i], bB[i], h11B);
+                    const f2 na = {-fx.a[i], -fx.a[i]};
+                    h01A = __builtin_elementwise_fma(na, bA[i], h01A);
+                    h01B = __builtin_elementwise_fma(na, bB[i], h01B);
+                }
+                const f2 prodA = h00v * h11A, prodB = h00v * h11B;
+                const f2 lhsA = h01A * h01A, lhsB = h01B * h01B;
+                const f2 loA = prodA * t2lo, loB = prodB * t2lo, hiA = prodA * t2hi, hiB = prodB * t2hi;
+                // verdict masks (bit u = Y index g+u): pass = certainly separated, fail = certainly not
+                unsigned passm = 0u, failm = 0u;
+                passm |= (h11A.x >= kCondMin && lhsA.x < loA.x) ? 1u : 0u;
+                passm |= (h11A.y >= kCondMin && lhsA.y < loA.y) ? 2u : 0u;
+                passm |= (h11B.x >= kCondMin && lhsB.x < loB.x) ? 4u : 0u;
+                passm |= (h11B.y >= kCondMin && lhsB.y < loB.y) ? 8u : 0u;
+                failm |= (h11A.x >= kCondMin && lhsA.x > hiA.x) ? 1u : 0u;
+                failm |= (h11A.y >= kCondMin && lhsA.y > hiA.y) ? 2u : 0u;
+                failm |= (h11B.x >= kCondMin && lhsB.x > hiB.x) ? 4u : 0u;
+                failm |= (h11B.y >= kCondMin && lhsB.y > hiB.y) ? 8u : 0u;
+                if (fx.ill)
+                {
+                    passm = 0u;
+                    failm = 0u;
+                }
+                ntests += __popc(livem);
+                unsigned todo = livem & ~failm;  // separated or uncertain: leaves the straight line
+                while (todo)
+                {
+                    const int u = __ffs(todo) - 1;
+                    todo &= todo - 1;
+                    const int k2 = g + u;
+                    if ((passm >> u) & 1u)
+                    {
+                        bool first;
+                        if constexpr (MODE == 0)
+                        {
+                            const unsigned long long old = atomicMin(&p.best[o0 + k2], rank);
+                            atomicMin(&s_rel[k2], myrel);
+                            first = (old == kNone);
+                            if (first) atomicAdd(&p.rowfound[X], 1);
+                        }
+                        else
+                        {
+                            first = clear_edge(p.adj, p.deg, p.words, X, s_nbr[k2]);
+                            s_rel[k2] = 0u;
+                        }
+                        if (first) nrem++;
+                    }
+                    else
+                    {
+                        const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
+                        if (qi < p.qcap)
+                        {
+                            RecheckEntry en;
+                            en.x = X;
+                            en.k2 = k2;
+                            en.rank = rank;
+                            p.queue[qi] = en;
+                        }
+                    }
+                }
+            }
+            if (!anyalive) break;
+            // next combination
+            {
+                int i = L - 1;
+                while (i >= 0 && idx[i] == d - L + i) i--;
+                if (i < 0) break;
+                idx[i]++;
+                for (int j2 = i + 1; j2 < L; j2++) idx[j2] = idx[j2 - 1] + 1;
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);
+        nsub += __shfl_xor(nsub, o);
+        nrem += __shfl_xor(nrem, o);
+    }
+    if ((tid & 63) == 0)
+    {
+        if (ntests) atomicAdd(&s_cnt[0], ntests);
+        if (nsub) atomicAdd(&s_cnt[1], nsub);
+        if (nrem) atomicAdd(&s_cnt[2], nrem);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        for (int i = 0; i < 3; i++)
+            if (s_cnt[i]) atomicAdd(&sl[i], s_cnt[i]);
+    }
+}
+
+size_t sweep_vec_lds_bytes(int cls) { return vec_layout(kClassCap[cls]).total; }
+
+template <int L, int MODE>
+static hipError_t launch_vec_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    if (nitems <= 0) return hipSuccess;
+    const size_t lds = vec_layout(kClassCap[cls]).total;
+    auto kfn = sweep_vec_kernel<L, MODE>;
+    if (lds > 64 * 1024)
+    {
+        hipError_t e =
+            hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st)
+{
+    switch (L)
+    {
+#define CUSK_CASE(LL) \
+    case LL: return mode == 0 ? launch_vec_L<LL, 0>(p, cls, nitems, st) : launch_vec_L<LL, 1>(p, cls, nitems, st);
+        CUSK_CASE(2)
+        CUSK_CASE(3)
+        CUSK_CASE(4)
+        CUSK_CASE(5)
+        CUSK_CASE(6)
+        CUSK_CASE(7)
+        CUSK_CASE(8)
+        CUSK_CASE(9)
+        CUSK_CASE(10)
+        CUSK_CASE(11)
+        CUSK_CASE(12)
+        CUSK_CASE(13)
+        CUSK_CASE(14)
+#undef CUSK_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cusk
