@@ -634,6 +634,25 @@ extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *le
     return c;
 }
 
+extern "C" int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host)
+{
+    if (!e || !M_dev || !idx_host || !out_host || k <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    int *idx_d = nullptr;
+    float *out_d = nullptr;
+    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&idx_d), sizeof(int) * (size_t)k));
+    hipError_t st = hipMalloc(reinterpret_cast<void **>(&out_d), sizeof(float) * (size_t)k * k);
+    if (st == hipSuccess) st = hipMemcpyAsync(idx_d, idx_host, sizeof(int) * (size_t)k, hipMemcpyHostToDevice, e->stream);
+    if (st == hipSuccess) st = launch_gather_sub(M_dev, n, idx_d, k, out_d, e->stream);
+    if (st == hipSuccess)
+        st = hipMemcpyAsync(out_host, out_d, sizeof(float) * (size_t)k * k, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    (void)hipFree(idx_d);
+    (void)hipFree(out_d);
+    if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    return CUSK_OK;
+}
+
 extern "C" void *cusk_dev_alloc(size_t bytes)
 {
     void *p = nullptr;

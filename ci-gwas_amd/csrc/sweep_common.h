@@ -158,6 +158,7 @@ hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, 
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
+hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);
 hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,
                               int n, int words, const int *x, const int *y, const float *z, long long nrec, hipStream_t st);

@@ -598,4 +598,18 @@ hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long
     return hipGetLastError();
 }
 
+// out[a * k + b] = M[idx[a] * n + idx[b]]
+__global__ void gather_sub_kernel(const float *__restrict__ M, int n, const int *__restrict__ idx, int k, float *out)
+{
+    const int a = blockIdx.y;
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < k) out[(size_t)a * k + b] = M[(size_t)idx[a] * n + idx[b]];
+}
+
+hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(gather_sub_kernel, dim3((k + 255) / 256, k), dim3(256), 0, st, M, n, idx, k, out);
+    return hipGetLastError();
+}
+
 }  // namespace cusk

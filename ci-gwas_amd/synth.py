@@ -146,3 +146,34 @@ def random_corr(n: int, seed: int, k: int | None = None, strength: float = 1.0) 
     Cm = Cm + Cm.T
     np.fill_diagonal(Cm, 1.0)
     return np.ascontiguousarray(Cm, np.float32)
+
+
+def write_bfiles(stem: str, bed: np.ndarray, N: int, means, stds, chr_ids=None) -> None:
+    """<stem>.bed/.bim/.fam/.dim/.means/.stds as the reference's `mps prep` leaves them
+    (reference io.h:30-64, prep.cpp:157-201, bfiles_base.h:8-9)."""
+    m = bed.shape[0]
+    chr_ids = chr_ids if chr_ids is not None else ["1"] * m
+    with open(stem + ".bed", "wb") as f:
+        f.write(bytes([0x6C, 0x1B, 0x01]))
+        f.write(np.ascontiguousarray(bed, np.uint8).tobytes())
+    with open(stem + ".bim", "w") as f:
+        for i in range(m):
+            f.write(f"{chr_ids[i]}\trs{i}\t0\t{1000 + i}\tA\tG\n")
+    with open(stem + ".fam", "w") as f:
+        for i in range(N):
+            f.write(f"f{i} i{i} 0 0 0 -9\n")
+    with open(stem + ".dim", "w") as f:
+        f.write(f"{N}\t{m}\n")
+    for sfx, arr in ((".means", means), (".stds", stds)):
+        with open(stem + sfx, "w") as f:
+            for v in np.asarray(arr, np.float32):
+                f.write(repr(float(v)) + "\n")
+
+
+def write_phen(path: str, phen_colmajor: np.ndarray, N: int, p: int) -> None:
+    """header + `FID IID v1..vp` rows, NaN written as NA (reference phen.cpp:9-74)."""
+    Y = np.asarray(phen_colmajor, np.float32).reshape(p, N)
+    with open(path, "w") as f:
+        f.write("FID IID " + " ".join(f"T{k}" for k in range(p)) + "\n")
+        for i in range(N):
+            f.write(f"f{i} i{i} " + " ".join("NA" if np.isnan(Y[k, i]) else repr(float(Y[k, i])) for k in range(p)) + "\n")

@@ -160,6 +160,10 @@ int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen,
 /* timing of the last cusk_corr_build: [0] decode, [1] count GEMM, [2] mxp/pxp, [3] total (ms) */
 void cusk_corr_timing(const cusk_engine *e, float *ms4);
 
+/* out_host[a*k + b] = M_dev[idx[a]*n + idx[b]]: the retained sub-matrix of parent_set.cpp:84-238
+ * (reduce_gc / reduce_gcs) without copying the n*n matrix to the host; idx_host has k entries. */
+int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host);
+
 /* device memory helpers so that C hosts need no HIP headers */
 void *cusk_dev_alloc(size_t bytes);
 void cusk_dev_free(void *p);

@@ -1,0 +1,152 @@
+"""GPU: the `mps`-compatible host program end to end (argv in, result files out)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+MPS = os.path.join(ROOT, "ci-gwas_amd", "csrc", "mps")
+
+
+def _run(argv, env=None):
+    r = subprocess.run([MPS] + argv, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout
+
+
+@pytest.mark.parametrize("case", ["cuskss_trait_only", "cuskss_two_stage_merged", "cuskss_two_stage_block"])
+def test_cuskss_reference_fixtures(kat, golden_dir, tmp_path, case):
+    """the three end-to-end cases of the reference's tests/cuskss_tests.cpp"""
+    k = kat[case]
+    g = lambda f: os.path.join(golden_dir, f)
+    # through argv "trait only" means mxm == NULL, which the reference's mps.cpp:60-63 only accepts together with a
+    # block file (a merged run insists on mxm/mxp); the reference's test builds CuskssArgs by hand instead
+    merged = k["merged"] and not k["trait_only"]
+    argv = ["cuskss",
+            "NULL" if k["trait_only"] else g(k["mxm"]), "NULL" if k["trait_only"] else g(k["mxp"]), "NULL",
+            g(k["pxp"]), "NULL", "NULL", str(k.get("block_index", 0)),
+            g(k.get("blocks", "blocks.txt")) if not merged else "NULL", g(k["marker_ixs"]) if merged else "NULL",
+            str(k["alpha"]), str(k["max_level_one"]), str(k["max_level_two"]), str(k["depth"]), str(k["num_samples"]),
+            str(tmp_path)]
+    _run(argv)
+    base = str(tmp_path / k["stem"])
+    assert list(np.fromfile(base + ".adj", np.int32)) == k["exp_adj"]
+    assert np.allclose(np.fromfile(base + ".corr", np.float32), k["exp_corr"], atol=k["tol"], rtol=0)
+    if "exp_ixs" in k:
+        assert list(np.fromfile(base + ".ixs", np.int32)) == k["exp_ixs"]
+    nv, nph, ml = [int(v) for v in open(base + ".mdim").read().split()]
+    assert nph == 3 and ml == 14 and nv * nv == len(k["exp_adj"])
+    assert not os.path.exists(base + ".sep")
+
+
+def _write_cuskss_inputs(tmp_path, oracle, synth, m, p, het, seed):
+    rng = np.random.default_rng(seed)
+    Cm = synth.synth_corr_block(m, p, N=4096, block_index=seed)
+    names = [f"T{k}" for k in range(p)]
+    # mxm: lower triangle incl. diagonal
+    il = np.tril_indices(m)
+    Cm[:m, :m][il].astype(np.float32).tofile(tmp_path / "mxm.bin")
+    se_mp = rng.uniform(0.012, 0.02, (m, p))
+    se_pp = rng.uniform(0.012, 0.02, (p, p))
+    with open(tmp_path / "mxp.txt", "w") as f, open(tmp_path / "mxp_se.txt", "w") as g:
+        f.write("chr snp ref " + " ".join(names) + "\n")
+        g.write("chr snp ref " + " ".join(names) + "\n")
+        for i in range(m):
+            vals = [repr(float(Cm[i, m + k])) for k in range(p)]
+            if i == 7:
+                vals[1] = "NA"
+            f.write(f"1 rs{i} A " + " ".join(vals) + "\n")
+            g.write(f"1 rs{i} A " + " ".join(repr(float(se_mp[i, k])) for k in range(p)) + "\n")
+    with open(tmp_path / "pxp.txt", "w") as f, open(tmp_path / "pxp_se.txt", "w") as g:
+        f.write(" ".join(names) + "\n")
+        g.write(" ".join(names) + "\n")
+        for a in range(p):
+            f.write(names[a] + " " + " ".join(repr(float(Cm[m + a, m + b])) for b in range(p)) + "\n")
+            g.write(names[a] + " " + " ".join(repr(float(se_pp[a, b])) for b in range(p)) + "\n")
+    with open(tmp_path / "blocks.txt", "w") as f:
+        f.write(f"1\t0\t{m - 1}\n")
+    with open(tmp_path / "time_index.txt", "w") as f:
+        for k in range(p):
+            f.write(f"{1 + k % 3}\n")
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_cuskss_files_match_oracle_pipeline(oracle, synth, tmp_path, het):
+    m, p = 250, 6
+    _write_cuskss_inputs(tmp_path, oracle, synth, m, p, het, seed=91)
+    t = lambda f: str(tmp_path / f)
+    out = tmp_path / "out"
+    out.mkdir()
+    _run(["cuskss", t("mxm.bin"), t("mxp.txt"), t("mxp_se.txt") if het else "NULL", t("pxp.txt"),
+          t("pxp_se.txt") if het else "NULL", t("time_index.txt"), "0", t("blocks.txt"), "NULL", "0.0001", "3", "2", "1",
+          "4096", str(out)])
+    # oracle pipeline on the same files
+    mxm = oracle.load_mxm(t("mxm.bin"))
+    _, pxp, ess_p = oracle.load_pxp(t("pxp.txt"), sample_size=4096.0, se_path=t("pxp_se.txt") if het else None)
+    mxp, ess_mp = oracle.load_mxp(t("mxp.txt"), range(m), se_path=t("mxp_se.txt") if het else None)
+    sq, es = oracle.make_square_cuskss_inputs(mxm, mxp, pxp, 4096.0, ess_mp if het else None, ess_p if het else None)
+    ti = np.loadtxt(t("time_index.txt"), dtype=np.int32)
+    ref = oracle.cuskss_from_square(sq, es, p, 1e-4, 3, 2, 1, ti)
+    oracle.write_reduced(ref, t("ref"), with_sep=False)
+    for ext in (".mdim", ".ixs", ".adj", ".corr"):
+        assert open(str(out / f"1_0_{m - 1}") + ext, "rb").read() == open(t("ref") + ext, "rb").read(), ext
+
+
+def test_cusk_block_files_match_oracle_pipeline(oracle, synth, tmp_path):
+    m, N, p = 300, 2000, 4
+    bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=17, miss=0.003)
+    phen = phen.copy()
+    phen[5] = np.nan
+    stem = str(tmp_path / "geno")
+    chr_ids = ["1"] * 100 + ["2"] * 200  # the block sits on the second chromosome
+    synth.write_bfiles(stem, bed, N, means, stds, chr_ids)
+    synth.write_phen(str(tmp_path / "y.phen"), phen, N, p)
+    with open(tmp_path / "b.blocks", "w") as f:
+        f.write("1\t0\t99\n2\t10\t159\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, CUSK_WRITE_FULL_CORRMATS="1")
+    _run(["cusk", str(tmp_path / "y.phen"), stem, str(tmp_path / "b.blocks"), "0.001", "3", "14", "1", str(out), "1"], env)
+    base = str(out / "2_10_159")
+    mb = 150
+    n = mb + p
+    sq = np.fromfile(base + ".all_corrs", np.float32).reshape(n, n)
+    # the matrix the sweep ran on vs the oracle's correlation build on the same block
+    sel = slice(110, 260)
+    phen_rt = oracle.load_phen(str(tmp_path / "y.phen"))[2]
+    o_mxm, o_mxp, o_pxp = oracle.corr_pearson_npn(bed[sel], phen_rt, mb, N, p, means[sel], stds[sel])
+    want = oracle.square_from_cusk_corrs(o_mxm, o_mxp, o_pxp, mb, p)
+    assert np.array_equal(sq[:mb, :mb], want[:mb, :mb])
+    assert np.allclose(sq, want, atol=1e-5, rtol=0)
+    # result files vs the oracle's two-stage pipeline on that very matrix
+    Th = oracle.threshold_array(N, 0.001)
+    ref = oracle.cusk_from_corr(sq, p, Th, 3, 14, 1)
+    oracle.write_reduced(ref, str(tmp_path / "ref"), with_sep=True)
+    for ext in (".mdim", ".ixs", ".adj", ".corr", ".sep"):
+        assert open(base + ext, "rb").read() == open(str(tmp_path / "ref") + ext, "rb").read(), ext
+
+
+def test_cusk_skips_block_without_signal(synth, tmp_path):
+    m, N, p = 64, 500, 2
+    bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=3)
+    rng = np.random.default_rng(0)
+    phen = rng.standard_normal(p * N).astype(np.float32)  # traits unrelated to the markers
+    stem = str(tmp_path / "g")
+    synth.write_bfiles(stem, bed, N, means, stds)
+    synth.write_phen(str(tmp_path / "y.phen"), phen, N, p)
+    with open(tmp_path / "b.blocks", "w") as f:
+        f.write("1\t0\t63\n")
+    out = tmp_path / "out"
+    out.mkdir()
+    txt = _run(["cusk", str(tmp_path / "y.phen"), stem, str(tmp_path / "b.blocks"), "1e-12", "2", "2", "1", str(out), "0"])
+    assert "Skipping block" in txt and not list(out.iterdir())
+
+
+def test_error_paths(tmp_path):
+    r = subprocess.run([MPS, "cusk", "nope.phen", "nope", "nope.blocks", "0.1", "1", "1", "1", str(tmp_path), "0"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1
+    r = subprocess.run([MPS, "prep", "x"], capture_output=True, text=True)
+    assert r.returncode != 0
