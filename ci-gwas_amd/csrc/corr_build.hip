@@ -168,6 +168,181 @@ __global__ void __launch_bounds__(256) mxm_popcount_kernel(const unsigned long l
         }
 }
 
+// ---------------------------------------------------------------------------
+// SNP x SNP contingency counts as an int8 MFMA GEMM, decoded from .bed on the fly.
+//
+// Every cell of the 3x3 table of a marker pair is a dot product over individuals of two 0/1
+// indicator vectors.  With the planes X in {[g==1], [g==2], [non-missing]} the nine products
+// X_a(rows) . X_b(cols)^T are nine int8 GEMMs with exact int32 accumulation
+// (v_mfma_i32_32x32x32_i8: 32x32 outputs, 32 individuals per instruction).
+//
+// Workgroup = 256 threads = 4 waves (2x2), output tile 64 x 64 marker pairs, K block = 128
+// individuals.  Per K block each thread loads 16 bytes of packed .bed (64 individuals of one of
+// the 128 tile markers), expands them with bit logic + one multiply per 4 individuals into the
+// three int8 planes and stores them to LDS in MFMA fragment order (48 KB: [plane][k-step][half]
+// [row] x 16 B, so every fragment is one conflict-free ds_read_b128).  Each wave then issues
+// 4 k-steps x 9 MFMAs on its 32 x 32 sub-tile (9 accumulators = 144 VGPRs).  HBM traffic is the
+// packed .bed itself (2 bits per genotype); the int8 planes exist only in LDS.  Two workgroups
+// per CU overlap one's decode with the other's MFMAs.  The epilogue converts the counts to
+// floats and applies the reference's tau-b -> sin(pi/2 tau) formula in its fp32 operation order,
+// writing both triangles of the square matrix with coalesced rows (transpose through LDS).
+// Only tiles of the upper triangle are launched.
+// ---------------------------------------------------------------------------
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+constexpr int kMT = 64;    // markers per tile side
+constexpr int kKB = 128;   // individuals per K block
+constexpr int kKS = kKB / 32;
+
+// 16 genotype indicator bits at even positions of x -> 16 bytes of 0/1
+__device__ __forceinline__ v4i expand16(unsigned x)
+{
+    v4i o;
+    o.x = (int)((((x)&0x55u) * 0x00041041u) & 0x01010101u);
+    o.y = (int)((((x >> 8) & 0x55u) * 0x00041041u) & 0x01010101u);
+    o.z = (int)((((x >> 16) & 0x55u) * 0x00041041u) & 0x01010101u);
+    o.w = (int)((((x >> 24) & 0x55u) * 0x00041041u) & 0x01010101u);
+    return o;
+}
+
+__global__ void __launch_bounds__(256, 2) mxm_mfma_kernel(const unsigned char *__restrict__ bed, float *C, size_t m, size_t N,
+                                                           size_t clb, size_t n, int tiles)
+{
+    __shared__ v4i sA[3][kKS][2][kMT];
+    __shared__ v4i sB[3][kKS][2][kMT];
+    int t = blockIdx.x, bi = 0;
+    {
+        int rem = t, len = tiles;
+        while (rem >= len)
+        {
+            rem -= len;
+            len--;
+            bi++;
+        }
+        t = bi + rem;
+    }
+    const int bj = t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // decode role: tile-local marker (0..63 rows of A, 64..127 rows of B) and 64-individual half of the K block
+    const int row_l = tid >> 1, q = tid & 1;
+    const size_t mk = (row_l < kMT) ? (size_t)bi * kMT + row_l : (size_t)bj * kMT + (row_l - kMT);
+    const bool row_ok = mk < m;
+    const unsigned char *rowp = bed + mk * clb;
+    v4i(*dst)[kKS][2][kMT] = (row_l < kMT) ? sA : sB;
+    const int rr = row_l & (kMT - 1);
+
+    v16i acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0;
+
+    const size_t nkb = (N + kKB - 1) / kKB;
+    auto load16 = [&](size_t kb) -> uint4 {
+        uint4 w = make_uint4(0u, 0u, 0u, 0u);
+        const size_t off = kb * (kKB / 4) + (size_t)q * 16;
+        if (row_ok && off < clb)
+        {
+            const unsigned char *src = rowp + off;
+            if (off + 16 <= clb && ((reinterpret_cast<uintptr_t>(src) & 3u) == 0))
+            {
+                const unsigned *s4 = reinterpret_cast<const unsigned *>(src);
+                w = make_uint4(s4[0], s4[1], s4[2], s4[3]);
+            }
+            else
+            {
+                unsigned tmp[4] = {0u, 0u, 0u, 0u};
+                for (size_t b = 0; b < 16 && off + b < clb; b++) tmp[b >> 2] |= (unsigned)src[b] << (8 * (b & 3));
+                w = make_uint4(tmp[0], tmp[1], tmp[2], tmp[3]);
+            }
+        }
+        return w;
+    };
+    uint4 w = load16(0);
+    for (size_t kb = 0; kb < nkb; kb++)
+    {
+        const unsigned wu[4] = {w.x, w.y, w.z, w.w};
+        const size_t base = kb * kKB + (size_t)q * 64;
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+        {
+            // 16 individuals; those at or beyond N (padding bits, or past the file) count as missing
+            const size_t s0 = base + 16 * u;
+            const unsigned nv = (!row_ok || s0 >= N) ? 0u : (unsigned)min((size_t)16, N - s0);
+            const unsigned msk = (nv >= 16u) ? 0x55555555u : (((1u << (2 * nv)) - 1u) & 0x55555555u);
+            const unsigned lo = wu[u] & 0x55555555u, hi = (wu[u] >> 1) & 0x55555555u;
+            const unsigned b1 = hi & ~lo & msk;         // code 10 -> genotype 1
+            const unsigned b2 = ~hi & ~lo & msk;        // code 00 -> genotype 2
+            const unsigned bv = (hi | ~lo) & msk;       // anything but 01 (missing)
+            const int ks = 2 * q + (u >> 1), h = u & 1;
+            dst[0][ks][h][rr] = expand16(b1);
+            dst[1][ks][h][rr] = expand16(b2);
+            dst[2][ks][h][rr] = expand16(bv);
+        }
+        if (kb + 1 < nkb) w = load16(kb + 1);  // in flight while the MFMAs run
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < kKS; ks++)
+        {
+            v4i a[3], b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+            {
+                a[pl] = sA[pl][ks][lane >> 5][wr * 32 + (lane & 31)];
+                b[pl] = sB[pl][ks][lane >> 5][wc * 32 + (lane & 31)];
+            }
+#pragma unroll
+            for (int pa = 0; pa < 3; pa++)
+#pragma unroll
+                for (int pb = 0; pb < 3; pb++)
+                    acc[pa][pb] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[pa], b[pb], acc[pa][pb], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *scratch = reinterpret_cast<float *>(&sA[0][0][0][0]) + wave * (32 * 33);
+    const size_t i0 = (size_t)bi * kMT + wr * 32, j0 = (size_t)bj * kMT + wc * 32;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), cl = lane & 31;
+        const size_t i = i0 + rl, j = j0 + cl;
+        float r = 0.0f;
+        if (i < m && j < m && i < j)
+        {
+            const unsigned n11 = acc[0][0][e], n12 = acc[0][1][e], n21 = acc[1][0][e], n22 = acc[1][1][e],
+                           n1v = acc[0][2][e], n2v = acc[1][2][e], nv1 = acc[2][0][e], nv2 = acc[2][1][e],
+                           nvv = acc[2][2][e];
+            float s[9];
+            s[4] = (float)n11;
+            s[5] = (float)n12;
+            s[7] = (float)n21;
+            s[8] = (float)n22;
+            s[3] = (float)(n1v - n11 - n12);
+            s[6] = (float)(n2v - n21 - n22);
+            s[1] = (float)(nv1 - n11 - n21);
+            s[2] = (float)(nv2 - n12 - n22);
+            s[0] = (float)(nvv - n1v - n2v - (nv1 - n11 - n21) - (nv2 - n12 - n22));
+            r = npn_from_counts(s);
+            C[i * n + j] = r;
+        }
+        scratch[cl * 33 + rl] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int jl = 2 * e + (lane >> 5), il = lane & 31;
+        const size_t i = i0 + il, j = j0 + jl;
+        if (i < m && j < m && i < j) C[j * n + i] = scratch[jl * 33 + il];
+    }
+}
+
 // one wave per marker, all traits: Pearson of corr_kernels.cu:157-238
 constexpr int kMaxPhenRegs = 32;
 __global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restrict__ bed, const float *__restrict__ phen,
@@ -306,7 +481,6 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     CUSK_HIP(e, e->phen_dev.ensure(sizeof(float) * std::max<size_t>(p * N, 1)));
     CUSK_HIP(e, e->mean_dev.ensure(sizeof(float) * m));
     CUSK_HIP(e, e->std_dev.ensure(sizeof(float) * m));
-    CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
     CUSK_HIP(e, hipEventRecord(e->ev_corr[0], s));
     CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
     if (p) CUSK_HIP(e, hipMemcpyAsync(e->phen_dev.p, phen, sizeof(float) * p * N, hipMemcpyHostToDevice, s));
@@ -319,8 +493,10 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         mxp_d = e->mxp_dev.as<float>();
     }
     CUSK_HIP(e, hipEventRecord(e->ev_corr[1], s));
-    if (C_dev)
+    if (C_dev && e->opt_corr_popcount)
     {
+        // cross-check path: bit planes + AND/popcount (no matrix cores)
+        CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
         hipLaunchKernelGGL(bed_to_bitplanes_kernel, dim3((unsigned)((m * w64 + 255) / 256)), dim3(256), 0, s,
                            e->bed_dev.as<unsigned char>(), e->planes.as<unsigned long long>(), m, N, clb, w64);
         CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
@@ -328,6 +504,15 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         const long long nt = (long long)tiles * (tiles + 1) / 2;
         hipLaunchKernelGGL(mxm_popcount_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->planes.as<unsigned long long>(),
                            C_dev, m, w64, n, tiles);
+        hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C_dev, n);
+    }
+    else if (C_dev)
+    {
+        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
+        const int tiles = (int)((m + kMT - 1) / kMT);
+        const long long nt = (long long)tiles * (tiles + 1) / 2;
+        hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m, N,
+                           clb, n, tiles);
         hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C_dev, n);
     }
     else

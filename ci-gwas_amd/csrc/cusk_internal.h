@@ -88,6 +88,7 @@ struct cusk_engine
     int opt_validate = 0;
     int opt_pair = 1;
     int opt_vec = 1;
+    int opt_corr_popcount = 0;
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;

@@ -503,6 +503,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_pair = (int)value;
     else if (k == "vec")
         e->opt_vec = (int)value;
+    else if (k == "corr_popcount")
+        e->opt_corr_popcount = (int)value;
     else if (k == "assume_symmetric")
         e->opt_assume_symmetric = (int)value;
     else if (k == "queue_capacity" && value > 0)

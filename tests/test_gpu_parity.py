@@ -289,3 +289,23 @@ def test_corr_build_vs_oracle(cg, eng, oracle, synth, m, N, p):
     want = oracle.square_from_cusk_corrs(mxm, mxp, pxp, m, p)
     assert np.array_equal(sq, want, equal_nan=True) and np.array_equal(mxp3, mxp)
     Cd.free()
+
+
+def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth):
+    """the int8 MFMA contingency GEMM and the bit-plane popcount kernel give identical matrices"""
+    m, N, p = 200, 1500, 3
+    bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=4, miss=0.02)
+    n = m + p
+    outs = []
+    for popc in (0, 1):
+        e = cg.Engine(0)
+        e.set_option("corr_popcount", popc)
+        Cd = cg.DeviceArray(nbytes=4 * n * n)
+        e.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr)
+        outs.append(Cd.download(np.float32, (n, n)))
+        Cd.free()
+        e.close()
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    o_mxm, _, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
+    iu = np.triu_indices(m, 1)
+    assert np.array_equal(outs[0][:m, :m][iu], o_mxm, equal_nan=True)
