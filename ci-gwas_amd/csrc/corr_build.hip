@@ -410,6 +410,85 @@ __global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restric
     }
 }
 
+// SNP x trait Pearson, tiled: 16 markers per workgroup, 16 lanes per marker striding the
+// individuals; the traits' values of a 256-individual chunk are staged in LDS once and shared
+// by the 16 markers (the naive kernel above re-reads every trait from L2 for every marker).
+constexpr int kMxpChunk = 256;
+__global__ void __launch_bounds__(256) mxp_tile_kernel(const unsigned char *__restrict__ bed, const float *__restrict__ phen,
+                                                        const float *__restrict__ mean, const float *__restrict__ sd, float *C,
+                                                        float *mxp, size_t m, size_t N, size_t p, size_t clb, size_t n,
+                                                        size_t p0, int pcount)
+{
+    __shared__ float sy[kMaxPhenRegs][kMxpChunk];
+    const int tid = threadIdx.x, mi = tid >> 4, sl = tid & 15;
+    const size_t mk = (size_t)blockIdx.x * 16 + mi;
+    const bool ok = mk < m;
+    float sgy[kMaxPhenRegs], syv[kMaxPhenRegs], sn[kMaxPhenRegs];
+#pragma unroll
+    for (int k = 0; k < kMaxPhenRegs; k++) sgy[k] = syv[k] = sn[k] = 0.0f;
+    for (size_t c0 = 0; c0 < N; c0 += kMxpChunk)
+    {
+        __syncthreads();
+        for (int e = tid; e < pcount * kMxpChunk; e += 256)
+        {
+            const int t = e / kMxpChunk, s = e - t * kMxpChunk;
+            sy[t][s] = (c0 + s < N) ? phen[(p0 + t) * N + c0 + s] : __builtin_nanf("");
+        }
+        __syncthreads();
+        if (!ok) continue;
+#pragma unroll 4
+        for (int i = 0; i < kMxpChunk / 16; i++)
+        {
+            const int s = sl + 16 * i;
+            const size_t smp = c0 + s;
+            if (smp >= N) break;
+            const unsigned code = (bed[mk * clb + (smp >> 2)] >> (2 * (smp & 3))) & 3u;
+            const float valid = (code != 1u) ? 1.0f : 0.0f;
+            const float g = (code == 0u) ? 2.0f : ((code == 2u) ? 1.0f : 0.0f);
+            const float vg = valid * g;
+#pragma unroll
+            for (int k = 0; k < kMaxPhenRegs; k++)
+            {
+                if (k < pcount)
+                {
+                    const float y = sy[k][s];
+                    if (!(y != y))
+                    {
+                        sgy[k] += vg * y;
+                        syv[k] += valid * y;
+                        sn[k] += valid;
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < kMaxPhenRegs; k++)
+    {
+        if (k < pcount)
+        {
+            float a = sgy[k], b = syv[k], c = sn[k];
+            for (int o = 8; o > 0; o >>= 1)
+            {
+                a += __shfl_xor(a, o);
+                b += __shfl_xor(b, o);
+                c += __shfl_xor(c, o);
+            }
+            if (sl == 0 && ok)
+            {
+                const float r = (a - mean[mk] * b) / (c * sd[mk]);
+                const size_t t = p0 + k;
+                if (C)
+                {
+                    C[mk * n + m + t] = r;
+                    C[(m + t) * n + mk] = r;
+                }
+                if (mxp) mxp[mk * p + t] = r;
+            }
+        }
+    }
+}
+
 // one workgroup per trait pair (a < b): corr_kernels.cu:285-343
 __global__ void __launch_bounds__(256) pxp_kernel(const float *__restrict__ phen, float *C, size_t m, size_t N, size_t p,
                                                    size_t n)
@@ -523,9 +602,14 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
     {
         const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
-        hipLaunchKernelGGL(mxp_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
-                           e->phen_dev.as<float>(), e->mean_dev.as<float>(), e->std_dev.as<float>(), C_dev, mxp_d, m, N, p,
-                           clb, n, p0, pc);
+        if (e->opt_corr_popcount)
+            hipLaunchKernelGGL(mxp_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
+                               e->phen_dev.as<float>(), e->mean_dev.as<float>(), e->std_dev.as<float>(), C_dev, mxp_d, m, N,
+                               p, clb, n, p0, pc);
+        else
+            hipLaunchKernelGGL(mxp_tile_kernel, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s,
+                               e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
+                               e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
     }
     if (C_dev && p > 1)
         hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, e->phen_dev.as<float>(), C_dev, m,

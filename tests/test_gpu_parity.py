@@ -305,7 +305,8 @@ def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth):
         outs.append(Cd.download(np.float32, (n, n)))
         Cd.free()
         e.close()
-    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    assert np.array_equal(outs[0][:m, :m], outs[1][:m, :m], equal_nan=True)
+    assert np.allclose(outs[0], outs[1], atol=1e-6, rtol=0, equal_nan=True)  # SNP x trait: different summation orders
     o_mxm, _, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
     iu = np.triu_indices(m, 1)
     assert np.array_equal(outs[0][:m, :m][iu], o_mxm, equal_nan=True)
