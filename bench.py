@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--alpha", type=float, default=1e-4)
     ap.add_argument("--engine", choices=["cusk", "cuskss"], default="cusk",
                     help="cusk: Skeleton engine (sepsets + pMax); cuskss: hetcor engine with uniform ESS")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-markers", type=int, default=10000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(16, affinity))")
@@ -65,10 +66,16 @@ def main():
     import torch
     import torch.distributed as dist
 
+    ndev = torch.cuda.device_count()
+    local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
+    cdev = "cuda" if args.backend == "nccl" else "cpu"  # where the collectives' tensors live
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import cigwas_amd as cg
     from cigwas_amd import synth
@@ -93,7 +100,10 @@ def main():
 
     words = (n + 63) // 64
     if world > 1:
-        gather_out = [torch.empty((p, words), dtype=torch.int64, device="cuda") for _ in range(world)]
+        gather_out = [torch.empty((p, words), dtype=torch.int64, device=cdev) for _ in range(world)]
+        import ctypes as C
+
+        hip = C.CDLL("libamdhip64.so")
 
     def step():
         if args.engine == "cusk":
@@ -105,11 +115,11 @@ def main():
             from cigwas_amd._lib import lib as _lib
 
             base = _lib().cusk_result_adj_bits_dev(eng.h)
-            rows = torch.empty((p, words), dtype=torch.int64, device="cuda")
-            import ctypes as C
-
-            hip = C.CDLL("libamdhip64.so")
-            hip.hipMemcpy(C.c_void_p(rows.data_ptr()), C.c_void_p(base + 8 * words * m), C.c_size_t(8 * words * p), 3)
+            rows = torch.empty((p, words), dtype=torch.int64, device=cdev)
+            # kind 3 = device to device, 2 = device to host
+            rc = hip.hipMemcpy(C.c_void_p(rows.data_ptr()), C.c_void_p(base + 8 * words * m), C.c_size_t(8 * words * p),
+                               3 if cdev == "cuda" else 2)
+            assert rc == 0, f"hipMemcpy failed: {rc}"
             dist.all_gather(gather_out, rows)
         return st
 
@@ -132,10 +142,10 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        tt = torch.tensor([tests_total], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([tests_total], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.SUM)
         tests_total = float(tt.item())
 
