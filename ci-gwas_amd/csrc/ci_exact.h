@@ -236,11 +236,20 @@ __device__ __forceinline__ void pinv_courrieu(const float *M2, float *Inv)
         }
 }
 
-// svdcmp-based pseudo-inverse for M >= 4.  A (M x M row-major) is destroyed.
-template <int M>
-__device__ __noinline__ void pinv_svd(float *A, float *Inv)
+// Work arrays of the SVD kept in LDS, one element per lane at a stride of the workgroup size:
+// dynamic indexing then costs an LDS access (~64 cycles) instead of a scratch-memory round trip.
+struct StridedArr
 {
-    float V[M * M], w[M], rv1[M];
+    float *base;
+    int stride;
+    __device__ __forceinline__ float &operator[](int i) const { return base[i * stride]; }
+};
+
+// svdcmp-based pseudo-inverse for M >= 4.  A (M x M row-major) is destroyed; V (M x M), w and
+// rv1 (M each) are work arrays.  Arr is float* (private memory) or StridedArr (LDS).
+template <int M, typename Arr>
+__device__ __forceinline__ void pinv_svd_core(Arr A, Arr V, Arr w, Arr rv1, float *Inv)
+{
     int flag, its, i, j, jj, k, l = 0, nm = 0;
     float c, f, h, s, x, y, z;
     float anorm = 0.0f, g = 0.0f, scale = 0.0f;
@@ -452,16 +461,29 @@ __device__ __noinline__ void pinv_svd(float *A, float *Inv)
         }
     }
     // Inv = (V / w) * U^T ; V(i,k)/w[k] is formed first, as the reference does
-    for (i = 0; i < M; i++)
-        for (j = 0; j < M; j++)
+#pragma unroll
+    for (int ii = 0; ii < M; ii++)
+#pragma unroll
+        for (int jj2 = 0; jj2 < M; jj2++)
         {
             float acc = 0.0f;
-            for (k = 0; k < M; k++) acc = acc + (VV(i, k) / w[k]) * AA(j, k);
-            Inv[i * M + j] = acc;
+#pragma unroll
+            for (int kk = 0; kk < M; kk++) acc = acc + (VV(ii, kk) / w[kk]) * AA(jj2, kk);
+            Inv[ii * M + jj2] = acc;
         }
 #undef AA
 #undef VV
 }
+
+template <int M>
+__device__ __noinline__ void pinv_svd(float *A, float *Inv)
+{
+    float V[M * M], w[M], rv1[M];
+    pinv_svd_core<M, float *>(A, V, w, rv1, Inv);
+}
+
+// floats of LDS work space per lane for the exact path at conditioning-set size L
+__host__ __device__ constexpr int exact_ws_floats(int L) { return (L >= 4) ? (2 * L * L + 2 * L) : 0; }
 
 // M2 is L x L row-major and may be destroyed.
 template <int L>
@@ -490,6 +512,41 @@ struct SubsetExact
         if constexpr (L >= 2)
         {
             pinv_ref_order<L>(m2, inv);
+#pragma unroll
+            for (int c2 = 0; c2 < L; c2++)
+            {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c3 = 0; c3 < L; c3++) acc += m1x[c3] * inv[c3 * L + c2];
+                mmx[c2] = acc;
+            }
+            float h = 0.0f;
+#pragma unroll
+            for (int c3 = 0; c3 < L; c3++) h += mmx[c3] * m1x[c3];
+            h00 = h;
+        }
+    }
+
+    // same as prepare(), with the SVD work arrays in LDS: ws points at this lane's first float,
+    // consecutive floats of one lane are `stride` apart (exact_ws_floats(L) of them)
+    __device__ __forceinline__ void prepare_ws(const float *m2, const float *m1x_in, float *ws, int stride)
+    {
+        if constexpr (L < 4)
+        {
+            float tmp[(L > 1) ? L * L : 1];
+#pragma unroll
+            for (int a = 0; a < ((L > 1) ? L * L : 1); a++) tmp[a] = m2[a];
+            prepare(tmp, m1x_in);
+        }
+        else
+        {
+#pragma unroll
+            for (int a = 0; a < L; a++) m1x[a] = m1x_in[a];
+            StridedArr A{ws, stride}, V{ws + (size_t)L * L * stride, stride}, w{ws + (size_t)2 * L * L * stride, stride},
+                rv1{ws + (size_t)(2 * L * L + L) * stride, stride};
+#pragma unroll
+            for (int a = 0; a < L * L; a++) A[a] = m2[a];
+            pinv_svd_core<L, StridedArr>(A, V, w, rv1, inv);
 #pragma unroll
             for (int c2 = 0; c2 < L; c2++)
             {

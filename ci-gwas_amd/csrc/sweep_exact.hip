@@ -126,9 +126,12 @@ hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, i
 // exact evaluation of the queued tests: one lane per entry, operands straight from HBM/L2;
 // the entry count is read on the device (no host round trip), grid-stride loop
 // ---------------------------------------------------------------------------
+constexpr int kExactThreads = 64;  // lanes per workgroup of the rare-entry exact kernels (LDS work space per lane)
+
 template <int L, int MODE, bool HET>
-__global__ void __launch_bounds__(256) recheck_kernel(SweepParams p)
+__global__ void __launch_bounds__(kExactThreads) recheck_kernel(SweepParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float ws_lds[];
     const unsigned long long count = min(p.cnt->qcount, p.qcap);
     const int n = p.n;
     for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < count;
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) recheck_kernel(SweepParams p)
                         (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
         }
         SubsetExact<L> cx;
-        cx.prepare(m2, m1x);
+        cx.prepare_ws(m2, m1x, ws_lds + threadIdx.x, kExactThreads);
         const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
         float lth = p.th;
         if constexpr (HET)
@@ -200,18 +203,23 @@ __global__ void __launch_bounds__(256) recheck_kernel(SweepParams p)
 hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st)
 {
     // level 2 queues ~1e3 tests on a 10k block, deeper levels tens: a small grid-stride launch
-    const dim3 grid(L <= 3 ? 128 : 32), block(256);
+    const dim3 grid(L <= 3 ? 512 : 128), block(kExactThreads);
+    const size_t lds = sizeof(float) * (size_t)exact_ws_floats(L) * kExactThreads;
     switch (L)
     {
 #define CUSK_CASE(LL)                                                                             \
     case LL:                                                                                      \
-        if (mode == 0)                                                                            \
-            hipLaunchKernelGGL((recheck_kernel<LL, 0, false>), grid, block, 0, st, p);            \
-        else if (het)                                                                             \
-            hipLaunchKernelGGL((recheck_kernel<LL, 1, true>), grid, block, 0, st, p);             \
-        else                                                                                      \
-            hipLaunchKernelGGL((recheck_kernel<LL, 1, false>), grid, block, 0, st, p);            \
-        break;
+    {                                                                                             \
+        auto k0 = recheck_kernel<LL, 0, false>;                                                   \
+        auto k1 = recheck_kernel<LL, 1, true>;                                                    \
+        auto k2 = recheck_kernel<LL, 1, false>;                                                   \
+        auto kf = (mode == 0) ? k0 : (het ? k1 : k2);                                             \
+        if (lds > 64 * 1024)                                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kf),                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);      \
+        hipLaunchKernelGGL(kf, grid, block, lds, st, p);                                          \
+        break;                                                                                    \
+    }
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE
         default: return hipErrorInvalidValue;
@@ -281,8 +289,9 @@ __global__ void gather_records_kernel(FinalizeParams p)
 }
 
 template <int L>
-__global__ void __launch_bounds__(256) record_z_kernel(FinalizeParams p)
+__global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams p)
 {
+    extern __shared__ __attribute__((aligned(16))) float ws_lds[];
     const long long first = p.rec_base[p.level], count = p.rec_base[p.level + 1] - first;
     const int n = p.n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
@@ -309,7 +318,7 @@ __global__ void __launch_bounds__(256) record_z_kernel(FinalizeParams p)
                         (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
         }
         SubsetExact<L> cx;
-        cx.prepare(m2, m1x);
+        cx.prepare_ws(m2, m1x, ws_lds + threadIdx.x, kExactThreads);
         const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
         float z;
         (void)z_below<L == 1>(rho, 0.0f, &z);
@@ -321,13 +330,17 @@ hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
 {
     const dim3 grid((p.n + 3) / 4), block(256);
     // level 1 produces ~1e6 records on a 10k block, deeper levels a handful
-    const dim3 zgrid(L == 1 ? 2048 : 64);
+    const dim3 zgrid(L == 1 ? 8192 : 256), zblock(kExactThreads);
+    const size_t zlds = sizeof(float) * (size_t)exact_ws_floats(L) * kExactThreads;
     switch (L)
     {
 #define CUSK_CASE(LL)                                                          \
     case LL:                                                                   \
         hipLaunchKernelGGL(gather_records_kernel<LL>, grid, block, 0, st, p);  \
-        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, block, 0, st, p);       \
+        if (zlds > 64 * 1024)                                                      \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(record_z_kernel<LL>), \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)zlds); \
+        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, zblock, zlds, st, p);       \
         break;
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE
