@@ -186,7 +186,9 @@ def main():
                 "engine": args.engine,
             },
             "roofline": {
-                "kernel": f"sweep_kernel<L={lv}> (all degree classes of level {lv})",
+                "kernel": ("level1_pair_kernel<0>" if (lv == 1 and args.engine == "cusk") else
+                           ("level1_pair_kernel<1>" if lv == 1 else f"sweep_vec_kernel<{lv},{0 if args.engine == 'cusk' else 1}>"))
+                          + f" (the launches of level {lv}, one per degree class)",
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
@@ -195,8 +197,18 @@ def main():
                 "traffic": traffic,
                 "algorithmic_bytes_per_step": abytes,
                 "kernel_ms_per_step": float(kernel_ms[lv]),
-                "note": "algorithmic bytes = SURVEY 8(d): 4(l+l(l-1)/2) B per subset + 4(l+2) B per test; "
-                        "the engine serves them from an LDS-staged sub-matrix, so HBM traffic is far below this",
+                "note": "algorithmic bytes = SURVEY 8(d): 4(l+l(l-1)/2) B per subset + 4(l+2) B per test; level 1 reads one "
+                        "64-byte sector per 4-byte operand (scattered gathers of C[Y,S]), levels >= 2 run from an LDS-staged "
+                        "sub-matrix; traffic = FETCH_SIZE+WRITE_SIZE of the committed PMC passes (profiles/pmc_traffic.json)",
+            },
+            "corr_roofline": {
+                "kernel": "mxm_mfma_kernel (v_mfma_i32_32x32x32_i8, nine contingency GEMMs, upper-triangle tiles)",
+                "bound": "mfma",
+                "achieved": (2.0 * 9.0 * N * m * (m - 1) / 2.0) / (corr_ms[1] * 1e-3) / 1e12 if corr_ms[1] > 0 else 0.0,
+                "peak": 5000.0,
+                "unit": "TOP/s",
+                "frac": ((2.0 * 9.0 * N * m * (m - 1) / 2.0) / (corr_ms[1] * 1e-3) / 1e12) / 5000.0 if corr_ms[1] > 0 else 0.0,
+                "note": "ops = 2*9*N*m(m-1)/2 (SURVEY 8d); peak = dense int8 MFMA (2x the ~2.5 PF bf16 dense peak)",
             },
             "levels": {
                 str(l): {"tests": int(st.tests[l]), "subsets": int(st.subsets[l]), "removed": int(st.removed[l]), "rechecks": int(st.rechecks[l]),
