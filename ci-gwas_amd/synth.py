@@ -177,3 +177,52 @@ def write_phen(path: str, phen_colmajor: np.ndarray, N: int, p: int) -> None:
         f.write("FID IID " + " ".join(f"T{k}" for k in range(p)) + "\n")
         for i in range(N):
             f.write(f"f{i} i{i} " + " ".join("NA" if np.isnan(Y[k, i]) else repr(float(Y[k, i])) for k in range(p)) + "\n")
+
+
+def synth_corr_block_torch(m: int, p: int, N: int = 16384, block_index: int = 0, device: str = "cuda",
+                           window: int = 100, rho: float = 0.85):
+    """Full-size variant of synth_corr_block generated on the GPU with torch (plumbing only): same
+    generative model (LD windows with latent AR(1), MAF ~ U(0.05, 0.5), sparse SNP effects + trait DAG),
+    torch's generator instead of numpy's.  Returns a CUDA float32 tensor (m+p) x (m+p), symmetric, unit diagonal."""
+    import torch
+
+    g = torch.Generator(device=device)
+    g.manual_seed(BASE_SEED + int(block_index))
+    n = m + p
+    X = torch.empty((n, N), dtype=torch.float32, device=device)
+    s = (1.0 - rho * rho) ** 0.5
+    nrm = torch.distributions.Normal(0.0, 1.0)
+    for w0 in range(0, m, window):
+        w1 = min(m, w0 + window)
+        maf = torch.rand(w1 - w0, generator=g, device=device) * 0.45 + 0.05
+        thr = nrm.icdf(1.0 - maf).unsqueeze(1)
+        acc = torch.zeros((w1 - w0, N), dtype=torch.float32, device=device)
+        for _copy in range(2):
+            z = torch.randn((w1 - w0, N), generator=g, device=device)
+            for j in range(1, w1 - w0):
+                z[j] = rho * z[j - 1] + s * z[j]
+            acc += (z > thr).float()
+        X[w0:w1] = acc
+    Xs = X[:m] - X[:m].mean(1, keepdim=True)
+    Xs = Xs / Xs.std(1, keepdim=True).clamp_min(1e-6)
+    ncausal = max(1, int(round(5.0 * m / 1000.0)))
+    for k in range(p):
+        idx = torch.randint(0, m, (ncausal,), generator=g, device=device)
+        beta = (torch.rand(ncausal, generator=g, device=device) * 0.06 + 0.02) * (
+            torch.randint(0, 2, (ncausal,), generator=g, device=device).float() * 2 - 1)
+        y = beta @ Xs[idx]
+        for k2 in range(k):
+            if float(torch.rand(1, generator=g, device=device)) < 3.0 / p:
+                y = y + (0.05 + 0.15 * float(torch.rand(1, generator=g, device=device))) * X[m + k2]
+        y = y + torch.randn(N, generator=g, device=device)
+        X[m + k] = (y - y.mean()) / y.std()
+    del Xs
+    X -= X.mean(1, keepdim=True)
+    X /= X.norm(dim=1, keepdim=True).clamp_min(1e-30)
+    Cm = X @ X.T
+    del X
+    Cm.clamp_(-1.0, 1.0)
+    Cm = torch.triu(Cm, 1)
+    Cm = Cm + Cm.T
+    Cm.fill_diagonal_(1.0)
+    return Cm

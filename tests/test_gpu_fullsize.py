@@ -1,0 +1,121 @@
+"""GPU, BASELINE.json's full sizes (configs 3 and 5: 50k x 20 and 30k x 15 heterogeneous), beyond what the
+oracle (or the reference: SURVEY 0.9) can run -- size-independent properties instead of an element-wise oracle:
+symmetry, monotonicity, determinism, cross-engine agreement, and exact CPU re-evaluation of sampled decisions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ML = 14
+
+
+def _bits_to_deg(bits):
+    return np.array([int(np.unpackbits(r.view(np.uint8)).sum()) for r in bits])
+
+
+def _get(bits, i, j):
+    return (int(bits[i, j >> 6]) >> (j & 63)) & 1
+
+
+@pytest.mark.timeout(900)
+def test_config3_cuskss_50k_properties(oracle, synth):
+    import torch
+
+    import cigwas_amd as cg
+
+    m, p, N, alpha, lmax = 50000, 20, 16384, 1e-4, 2
+    n = m + p
+    Ct = synth.synth_corr_block_torch(m, p, N, block_index=3)
+    torch.cuda.synchronize()
+    eng = cg.Engine(0)
+    th = cg.hetcor_threshold(alpha)
+    ti = np.zeros(n, np.int32)
+    ti[m:] = 1
+    st = eng.run_hetcor(Ct.data_ptr(), n, th, lmax, ess_uniform=float(N), time_index=ti)
+    bits = eng.adjacency_bits()
+    assert st.level == lmax + 1 and st.tests[1] > 0 and st.exact_fallbacks == 0
+    # (1) undirected: bit (i,j) == bit (j,i) on a sample of rows; diagonal clear
+    rng = np.random.default_rng(0)
+    rows = np.concatenate([rng.integers(0, n, 300), np.arange(m, n)])
+    for i in rows:
+        nb = np.nonzero(np.unpackbits(bits[i].view(np.uint8), bitorder="little")[:n])[0]
+        assert i not in nb
+        for j in nb[:50]:
+            assert _get(bits, int(j), int(i)) == 1
+    # (2) deterministic: a second run gives the identical bitmap
+    st2 = eng.run_hetcor(Ct.data_ptr(), n, th, lmax, ess_uniform=float(N), time_index=ti)
+    assert np.array_equal(eng.adjacency_bits(), bits)
+    # (3) cross-engine: with a uniform sample size both engines threshold identically, so the Skeleton
+    #     engine (different kernels: pair kernel, min-rank selection, finaliser) must give the same graph
+    Th = cg.threshold_array(N, alpha)
+    st3 = eng.run_skeleton(Ct.data_ptr(), n, Th, lmax)
+    bits3 = eng.adjacency_bits()
+    assert np.array_equal(bits3, bits)
+    # (4) monotone: the final graph is a subgraph of the level-0 graph
+    st0 = eng.run_skeleton(Ct.data_ptr(), n, Th, 0)
+    bits0 = eng.adjacency_bits()
+    assert np.all((bits & ~bits0) == 0)
+    assert st0.level == 1
+    # (5) sampled separating sets re-evaluated exactly on the CPU (oracle arithmetic): z < threshold, members adjacent to X at level 0
+    eng.run_skeleton(Ct.data_ptr(), n, Th, lmax)
+    x, y, lv, z, S = eng.sepsets()
+    assert len(x) == sum(st3.removed[1:]) and len(x) > 1000
+    pick = rng.choice(len(x), 400, replace=False)
+    for r in pick:
+        idx = np.array([x[r], y[r]] + [s for s in S[r] if s >= 0])
+        sub = Ct[idx][:, idx].cpu().numpy()
+        rho, zz = oracle.ci_test(sub, 0, 1, np.arange(2, len(idx), dtype=np.int32))
+        assert zz < Th[lv[r]] and abs(zz - z[r]) <= 1e-6
+        for s in S[r]:
+            if s >= 0:
+                assert _get(bits0, int(x[r]), int(s)) == 1
+    eng.close()
+    del Ct
+
+
+@pytest.mark.timeout(900)
+def test_config5_cuskss_het_30k_properties(oracle, synth):
+    import torch
+
+    import cigwas_amd as cg
+
+    m, p, N, alpha, lmax = 30000, 15, 16384, 1e-4, 2
+    n = m + p
+    Ct = synth.synth_corr_block_torch(m, p, N, block_index=5)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    # per-pair effective sample sizes on the trait rows/columns (standard-error based): U(0.5, 1) N
+    Nt = torch.full((n, n), float(N), dtype=torch.float32, device="cuda")
+    e = (torch.rand((n, p), generator=g, device="cuda") * 0.5 + 0.5) * N
+    Nt[:, m:] = e
+    Nt[m:, :] = e.T
+    Nt[m:, m:] = torch.maximum(Nt[m:, m:], Nt[m:, m:].T)
+    torch.cuda.synchronize()
+    eng = cg.Engine(0)
+    th = cg.hetcor_threshold(alpha)
+    ti = np.zeros(n, np.int32)
+    ti[m:] = 1
+    st = eng.run_hetcor(Ct.data_ptr(), n, th, lmax, N_dev=Nt.data_ptr(), time_index=ti)
+    bits = eng.adjacency_bits()
+    assert st.level == lmax + 1 and st.exact_fallbacks == 0
+    st2 = eng.run_hetcor(Ct.data_ptr(), n, th, lmax, N_dev=Nt.data_ptr(), time_index=ti)
+    assert np.array_equal(eng.adjacency_bits(), bits)  # deterministic adjacency despite racing removals
+    # the filtered engine and the exact-only engine agree
+    eng.set_option("fast", 0)
+    st3 = eng.run_hetcor(Ct.data_ptr(), n, th, lmax, N_dev=Nt.data_ptr(), time_index=ti)
+    assert np.array_equal(eng.adjacency_bits(), bits)
+    eng.set_option("fast", 1)
+    # marker-marker pairs have ESS = N everywhere, so a uniform-ESS run can only differ on trait rows/columns
+    eng.run_hetcor(Ct.data_ptr(), n, th, 0, ess_uniform=float(N), time_index=ti)
+    b0u = eng.adjacency_bits()
+    eng.run_hetcor(Ct.data_ptr(), n, th, 0, N_dev=Nt.data_ptr(), time_index=ti)
+    b0h = eng.adjacency_bits()
+    w = (m + 63) // 64
+    diff = b0u ^ b0h
+    mask_last = np.uint64((1 << (m & 63)) - 1) if (m & 63) else np.uint64(0xFFFFFFFFFFFFFFFF)
+    d_mm = diff[:m, :w].copy()
+    if m & 63:
+        d_mm[:, w - 1] &= mask_last
+    assert not d_mm[:, : w].any()
+    # lower effective sample sizes raise thresholds: the heterogeneous level-0 graph is a subgraph of the uniform one
+    assert np.all((b0h & ~b0u) == 0)
+    eng.close()
