@@ -58,6 +58,8 @@ struct cusk_engine
 {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // auxiliary stream: independent degree classes, off-critical-path kernels
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_z = nullptr;
     bool own_stream = false;
     std::string err;
 
@@ -88,6 +90,7 @@ struct cusk_engine
     int opt_validate = 0;
     int opt_pair = 1;
     int opt_vec = 1;
+    int opt_overlap = 1;
     int opt_corr_popcount = 0;
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;

@@ -152,20 +152,39 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
         LevelPlan &pl = plan[l];
         SweepParams sp = pl.sp;
+        // The degree classes of a level are independent launches: the first non-empty class runs on the
+        // engine stream, the others on the auxiliary stream (many tiny rows next to a few hub rows fill the
+        // chip better together than one after the other); the streams join before the recheck pass.
+        int nonempty = 0;
+        for (int c = 0; c < kNumClasses; c++) nonempty += (pl.nitems[c] > 0);
+        const bool fork = (nonempty > 1) && (e->opt_overlap != 0);
+        if (fork)
+        {
+            CUSK_HIP(e, hipEventRecord(e->ev_fork, s));
+            CUSK_HIP(e, hipStreamWaitEvent(e->stream2, e->ev_fork, 0));
+        }
+        bool first = true;
         for (int c = 0; c < kNumClasses; c++)
         {
             if (pl.nitems[c] <= 0) continue;
+            hipStream_t cs = (fork && !first) ? e->stream2 : s;
+            first = false;
             sp.items = e->items[l & 1][c].as<int2>();
             sp.cap = kClassCap[c];
             if (pl.use_pair && !exact_only)
-                CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, s));
+                CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, cs));
             else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
                      sweep_vec_lds_bytes(c) <= kLdsLimit)
-                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, pl.nitems[c], s));
+                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, pl.nitems[c], cs));
             else if (pl.use_fast && !exact_only)
-                CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], s));
+                CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], cs));
             else
-                CUSK_HIP(e, launch_sweep_exact(a.mode, het, l, sp, c, pl.nitems[c], s));
+                CUSK_HIP(e, launch_sweep_exact(a.mode, het, l, sp, c, pl.nitems[c], cs));
+        }
+        if (fork)
+        {
+            CUSK_HIP(e, hipEventRecord(e->ev_join, e->stream2));
+            CUSK_HIP(e, hipStreamWaitEvent(s, e->ev_join, 0));
         }
         if (pl.use_fast && !exact_only) CUSK_HIP(e, launch_recheck(a.mode, het, l, sp, s));
         return CUSK_OK;
@@ -174,7 +193,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (a.mode != 0) return CUSK_OK;
         LevelPlan &pl = plan[l];
         CUSK_HIP(e, launch_rec_scan(e->rowfound[l & 1].as<int>(), e->recoff[l & 1].as<int>(), n, dcnt + l, drec_base, l, s));
-        CUSK_HIP(e, launch_finalize(l, pl.fp, s));
+        // the winners' exact z (record_z) is off the critical path: it runs on the auxiliary stream while
+        // the next level's compaction proceeds
+        CUSK_HIP(e, launch_finalize(l, pl.fp, s, e->opt_overlap ? e->stream2 : s, e->ev_z));
         return CUSK_OK;
     };
     auto sync_counters = [&]() -> int {
@@ -368,6 +389,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // final read-back (and a late overflow check for the last level that ran)
     for (;;)
     {
+        CUSK_HIP(e, hipEventRecord(e->ev_join, e->stream2));
+        CUSK_HIP(e, hipStreamWaitEvent(s, e->ev_join, 0));
         int rc = sync_counters();
         if (rc != CUSK_OK) return rc;
         const int redo = redo_if_overflowed(levels_swept);
@@ -441,6 +464,10 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         ok = ok && hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) == hipSuccess;
         e->own_stream = ok;
     }
+    ok = ok && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hcnt), sizeof(LevelCounters) * kLevels) == hipSuccess;
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hslots),
                              sizeof(unsigned long long) * kLevels * kCounterSlots * 4) == hipSuccess;
@@ -487,6 +514,10 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     for (int l = 0; l < kLevels; l++)
         for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
             if (ev) (void)hipEventDestroy(ev);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -503,6 +534,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_pair = (int)value;
     else if (k == "vec")
         e->opt_vec = (int)value;
+    else if (k == "overlap")
+        e->opt_overlap = (int)value;
     else if (k == "corr_popcount")
         e->opt_corr_popcount = (int)value;
     else if (k == "assume_symmetric")

@@ -138,7 +138,7 @@ __device__ __forceinline__ bool clear_edge(unsigned long long *adj, int *deg, in
 // sweep_exact.hip
 hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st);
 hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st);
-hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st);
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z);
 // sweep_fast.hip
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
                              hipStream_t st);

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams 
     }
 }
 
-hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z)
 {
     const dim3 grid((p.n + 3) / 4), block(256);
     // level 1 produces ~1e6 records on a 10k block, deeper levels a handful
@@ -337,10 +337,15 @@ hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
 #define CUSK_CASE(LL)                                                          \
     case LL:                                                                   \
         hipLaunchKernelGGL(gather_records_kernel<LL>, grid, block, 0, st, p);  \
+        if (st_z != st)                                                        \
+        {                                                                      \
+            (void)hipEventRecord(ev_z, st);                                    \
+            (void)hipStreamWaitEvent(st_z, ev_z, 0);                           \
+        }                                                                      \
         if (zlds > 64 * 1024)                                                      \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(record_z_kernel<LL>), \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)zlds); \
-        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, zblock, zlds, st, p);       \
+        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, zblock, zlds, st_z, p);     \
         break;
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE

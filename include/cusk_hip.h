@@ -113,7 +113,8 @@ const char *cusk_last_error(const cusk_engine *e);
  * arithmetic for every test), "validate" (default 0; 1: also run the exact path on every certified
  * verdict and count contradictions in cusk_stats.violations), "pair" (default 1: level-1 pair kernel on symmetric
  * matrices; 0: generic staged kernel), "vec" (default 1: vectorised
- * four-tests-per-ds_read_b128 sweep kernel; 0: scalar fast kernel), "corr_popcount" (default 0: int8 MFMA contingency GEMM in
+ * four-tests-per-ds_read_b128 sweep kernel; 0: scalar fast kernel), "overlap" (default 1: independent degree
+ * classes and the winners' exact z run on an auxiliary stream), "corr_popcount" (default 0: int8 MFMA contingency GEMM in
  * cusk_corr_build; 1: bit-plane AND/popcount cross-check kernel), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
  * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
