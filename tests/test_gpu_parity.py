@@ -310,3 +310,39 @@ def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth):
     o_mxm, _, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
     iu = np.triu_indices(m, 1)
     assert np.array_equal(outs[0][:m, :m][iu], o_mxm, equal_nan=True)
+
+
+def test_randomised_stress_against_oracle(cg, eng, oracle, synth):
+    """120 small random problems over sample size (down to barely more samples than variables: ill-conditioned
+    conditioning sets, NaN z, heavy use of the recheck path), density, alpha and max level; both engines."""
+    rng = np.random.default_rng(2025)
+    checked_levels = 0
+    for it in range(120):
+        n = int(rng.integers(4, 42))
+        k = int(rng.integers(n + 2, 12 * n))
+        alpha = float(rng.choice([0.01, 0.05, 0.2, 0.4]))
+        maxlevel = int(rng.integers(0, 9))
+        Cm = synth.random_corr(n, seed=1000 + it, k=k, strength=float(rng.uniform(0.6, 1.4)))
+        if it % 7 == 0:  # duplicate a variable: exactly singular conditioning sets
+            Cm[:, 1] = Cm[:, 0]
+            Cm[1, :] = Cm[0, :]
+            Cm[0, 1] = Cm[1, 0] = np.float32(0.999999)
+            np.fill_diagonal(Cm, 1)
+        Th = cg.threshold_array(max(k, 20), alpha)
+        ref = oracle.skeleton(Cm, Th, maxlevel)
+        Cd = cg.DeviceArray(Cm)
+        st = eng.run_skeleton(Cd.ptr, n, Th, maxlevel)
+        assert st.level == ref.level, (it, n, k, alpha, maxlevel)
+        assert np.array_equal(eng.adjacency(), ref.G), (it, n, k, alpha, maxlevel)
+        x, y, lv, z, S = eng.sepsets()
+        assert np.array_equal(_dense_sepsets(n, x, y, S), ref.sepset), (it, n, k, alpha, maxlevel)
+        th = cg.hetcor_threshold(alpha)
+        ti = np.zeros(n, np.int32)
+        ti[n // 2:] = rng.integers(0, 3, n - n // 2)
+        ess = float(max(k, 20))
+        ref2 = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), ess, np.float32), th, maxlevel, ti)
+        st2 = eng.run_hetcor(Cd.ptr, n, th, maxlevel, ess_uniform=ess, time_index=ti)
+        assert st2.level == ref2.level and np.array_equal(eng.adjacency(), ref2.G), (it, n, k, alpha, maxlevel)
+        checked_levels += st.levels_run
+        Cd.free()
+    assert checked_levels > 300
