@@ -74,6 +74,7 @@ struct cusk_engine
     cusk::DevBuf off[2], nbr[2], best[2], rowinfo[2], rowfound[2], recoff[2];
     cusk::DevBuf items[2][cusk::kNumClasses];
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
+    cusk::DevBuf rv, rpos;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors
     cusk::LevelCounters *hcnt = nullptr;   // kLevels entries
@@ -89,6 +90,7 @@ struct cusk_engine
     int opt_fast = 1;
     int opt_validate = 0;
     int opt_pair = 1;
+    int opt_rows = 1;
     int opt_vec = 1;
     int opt_overlap = 1;
     int opt_corr_popcount = 0;

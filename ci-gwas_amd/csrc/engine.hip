@@ -74,7 +74,7 @@ struct LevelPlan
     SweepParams sp;
     FinalizeParams fp;
     long long nitems[kNumClasses];
-    bool use_pair = false, use_fast = false;
+    bool use_pair = false, use_fast = false, use_rows = false, filter_ok = true;
     size_t pair_lds = 0;
     bool redone = false;
 };
@@ -155,6 +155,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         // The degree classes of a level are independent launches: the first non-empty class runs on the
         // engine stream, the others on the auxiliary stream (many tiny rows next to a few hub rows fill the
         // chip better together than one after the other); the streams join before the recheck pass.
+        if (pl.use_rows && !exact_only)
+        {
+            CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
+                                           e->rpos.p, s));
+            return CUSK_OK;
+        }
         int nonempty = 0;
         for (int c = 0; c < kNumClasses; c++) nonempty += (pl.nitems[c] > 0);
         const bool fork = (nonempty > 1) && (e->opt_overlap != 0);
@@ -239,8 +245,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 for (int k = 0; k < 2; k++)
                 {
                     CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
-                    if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
+                    if (a.mode == 0 || k == 1)  // hetcor uses `best` only as level-1 alive flags (set 1 = level 1)
+                        CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
                 }
+                CUSK_HIP(e, e->rv.ensure(sizeof(float) * (size_t)cap_edges));
+                CUSK_HIP(e, e->rpos.ensure(sizeof(int) * 4 * (size_t)cap_edges));
                 if (a.mode == 0)
                 {
                     CUSK_HIP(e, e->rec_x.ensure(sizeof(int) * (size_t)cap_edges));
@@ -276,11 +285,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             const int maxdeg_bound = (l == 1) ? e->hcnt[1].maxdeg : local.max_degree[l - 1];
             pl.pair_lds = (size_t)maxdeg_bound * 20 + 16;
             pl.use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
+            pl.use_rows = (l == 1) && !het && symmetric && (e->opt_pair != 0) && (e->opt_rows != 0);
             pl.use_fast = (e->opt_fast != 0) && (l >= 2);
             if (rebuilt)  // item_scan accumulates the class totals with atomics: start from zero again
                 CUSK_HIP(e, hipMemsetAsync(&dcnt[l].class_items[0], 0, sizeof(long long) * kNumClasses, s));
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
-                                        a.mode == 0 ? e->best[cs].as<unsigned long long>() : nullptr,
+                                        (a.mode == 0 || pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
                                         a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,
                                         e->binom.as<unsigned long long>(), chunk, staged_classes, pl.use_pair ? 1 : 0,
                                         e->rowinfo[cs].as<RowInfo>(), dcnt + l, s));
@@ -347,6 +357,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         {
             const double tq = std::tanh((double)sp.th);
             sp.t2 = (float)(tq * tq);
+            // The guard band of the filter (ci_fast.h) is relative; the fp32 Fisher z of the exact path carries an
+            // absolute error of ~1e-7.  Below this threshold the margin between the two gets thin, so such levels
+            // (N beyond ~4 million samples at alpha 1e-4) run entirely on the exact arithmetic.
+            pl.filter_ok = (sp.th >= kThMinFilter);
+            if (!pl.filter_ok) pl.use_fast = false;
         }
         sp.queue = nullptr;
         sp.qcap = 0;
@@ -495,7 +510,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->slots, &e->rec_base, &e->ti, &e->queue,
-                      &e->symflag, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+                      &e->symflag, &e->rv, &e->rpos, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)
@@ -532,6 +547,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_validate = (int)value;
     else if (k == "pair")
         e->opt_pair = (int)value;
+    else if (k == "rows")
+        e->opt_rows = (int)value;
     else if (k == "vec")
         e->opt_vec = (int)value;
     else if (k == "overlap")

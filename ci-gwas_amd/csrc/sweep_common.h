@@ -4,7 +4,8 @@
 
 namespace cusk {
 
-constexpr int kBinomStride = 16;  // binom[a * 16 + b] = C(a, b), b <= 15, saturating at 2^62
+constexpr int kBinomStride = 16;        // binom[a * 16 + b] = C(a, b), b <= 15, saturating at 2^62
+constexpr float kThMinFilter = 2e-3f;  // smallest Fisher-z threshold the fast filters are certified for
 
 struct RowInfo
 {
@@ -157,6 +158,8 @@ hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStre
 hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
+hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
+                              hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

@@ -2,7 +2,10 @@
 //
 // Replaces /root/reference/cusk/src/cuPC-S.cu:458-484 (cal_Indepl0), :6355-6432 (scan_compact),
 // :486-582 (cal_Indepl1) and their hetcor twins (src/hetcor-cuPC-S.cu:343-486).
+#include <algorithm>
+
 #include "ci_exact.h"
+#include "ci_fast.h"
 #include "sweep_common.h"
 
 namespace cusk {
@@ -530,6 +533,280 @@ hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t 
         hipLaunchKernelGGL(level1_pair_kernel<0>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
     else
         hipLaunchKernelGGL(level1_pair_kernel<1>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// level 1, row-streaming form (symmetric C, single threshold): HBM traffic = C once
+// ---------------------------------------------------------------------------
+// The pair kernel above pays one 64-byte HBM sector for every 4-byte operand C[Y,S].  Here the
+// loop nest is turned inside out: a workgroup owns one ROW ya of C, streams its upper part
+// C[ya, ya+1..n) into LDS with coalesced loads (the whole matrix is read exactly once over
+// the grid), and serves from LDS every level-1 test that needs an element of that row: for each
+// X adjacent to ya and each later neighbour yb of X, the element C[ya,yb] feeds the two tests
+// (X; ya | yb) and (X; yb | ya).  Everything else those tests need is per-edge data that was
+// compacted at level start and is read contiguously: the neighbour list of X, the gathered
+// row values rv = C[X, adj(X)], the selection state `best`, and rpos (position of ya inside
+// X's list).  One wave per X, lanes stride over yb.  For matrices wider than the LDS panel
+// the columns are processed in panels (blockIdx.y).
+
+// Per CSR slot (row, k) with Y = nbr_k:  rv = C[row, Y];  meta = {Y, position of row inside Y's ascending
+// list, start of Y's list, degree of Y}: everything a wave needs to start on one X of its row with one load.
+__global__ void level1_prep_kernel(const float *__restrict__ C, const int *__restrict__ off, const int *__restrict__ nbr,
+                                   float *rv, int4 *meta, int n)
+{
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int o0 = off[row], d = off[row + 1] - o0;
+    for (int k = lane; k < d; k += 64)
+    {
+        const int y = nbr[o0 + k];
+        rv[o0 + k] = C[(size_t)row * n + y];
+        const int oy = off[y];
+        const int dy = off[y + 1] - oy;
+        int lo = 0, hi = dy;
+        while (lo < hi)
+        {
+            const int mid = (lo + hi) >> 1;
+            if (nbr[oy + mid] < row)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        meta[o0 + k] = make_int4(y, lo, oy, dy);
+    }
+}
+
+struct RowsParams
+{
+    const float *rv;
+    const int4 *meta;
+    int panel_cols;
+    int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
+};
+
+constexpr int kRowsThreads = 1024;  // 16 waves share one staged row: 2 workgroups fill a CU's 32 wave slots
+
+// One level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|), decided against th.  The squared form with the
+// guard band of ci_fast.h settles almost every test in a handful of multiplies; the rest (inside
+// the band, |r| > 0.992 operands, NaN) take the reference's operation order.  VALIDATE: both, counted.
+template <bool VALIDATE>
+__device__ __forceinline__ bool level1_decide(float h00, float h01, float hc, float th, float t2, bool use_filter,
+                                              unsigned long long &viol)
+{
+    int fast = kUnsure;
+    if (use_filter && h00 >= kCondMin && hc >= kCondMin)
+    {
+        const float lhs = h01 * h01;
+        const float rhs = t2 * (h00 * hc);
+        if (lhs < rhs * (1.0f - kBeta))
+            fast = kPass;
+        else if (lhs > rhs * (1.0f + kBeta))
+            fast = kFail;
+    }
+    if (!VALIDATE && fast != kUnsure) return fast == kPass;
+    const float rho = h01 / (sqrtf(fabsf(h00)) * sqrtf(fabsf(hc)));
+    const bool ex = z_below<true>(rho, th);
+    if (VALIDATE && fast != kUnsure && (fast == kPass) != ex) viol++;
+    return ex;
+}
+
+template <int MODE, bool VALIDATE>
+__global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) level1_rows_kernel(SweepParams p, RowsParams rp)
+{
+    extern __shared__ __attribute__((aligned(16))) float s_row[];
+    __shared__ unsigned long long s_cnt[4];
+    const int ya = blockIdx.x;
+    const int n = p.n;
+    const int o0 = p.off[ya];
+    const int d = p.off[ya + 1] - o0;
+    const int pb = blockIdx.y * rp.panel_cols, pe = min(n, pb + rp.panel_cols);
+    const int lo = max(ya + 1, pb);
+    if (d == 0 || lo >= pe) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kRowsThreads >> 6;
+    if (tid < 4) s_cnt[tid] = 0ull;
+    int4 m = make_int4(0, 0, 0, 0);
+    if (wave < d) m = rp.meta[o0 + wave];
+    {
+        const float *src = p.C + (size_t)ya * n;
+        for (int j = lo + tid; j < pe; j += kRowsThreads) s_row[j - lo] = src[j];
+    }
+    __syncthreads();
+    [[maybe_unused]] int tiA = 0;
+    if constexpr (MODE == 1) tiA = p.time_index[ya];
+    const bool use_filter = rp.use_filter != 0;
+    const float th = p.th, t2 = p.t2;
+    unsigned long long ntests = 0, nrem = 0, viol = 0;
+    for (int k = wave; k < d; k += kWaves)
+    {
+        const int X = m.x, a = m.y, oX = m.z, dX = m.w;
+        if (k + kWaves < d) m = rp.meta[o0 + k + kWaves];  // next X of this wave: in flight during this one
+        if (a + 1 >= dX) continue;
+        // the last neighbour of X that can lie inside this panel bounds the scan; lists ascend
+        const float ra = rp.rv[oX + a];
+        const float h00b = 1.0f - (ra * ra);
+        [[maybe_unused]] int tiX = 0;
+        if constexpr (MODE == 1) tiX = p.time_index[X];
+        unsigned long long bestA = p.best[oX + a];
+        for (int b0 = a + 1; b0 < dX; b0 += 64)
+        {
+            const int b = b0 + lane;
+            bool act = b < dX;
+            int yb = 0;
+            if (act)
+            {
+                yb = p.nbr[oX + b];
+                act = (yb >= lo) && (yb < pe);
+            }
+            bool needA = false, needB = false;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
+            if (act)
+            {
+                const unsigned long long bestB = p.best[oX + b];
+                if constexpr (MODE == 0)
+                {
+                    needA = bestA >= (unsigned long long)b;
+                    needB = bestB >= (unsigned long long)a;
+                }
+                else
+                {
+                    const int tiB = p.time_index[yb];
+                    needA = (bestA == kNone) && !(tiB > max(tiX, tiA));
+                    needB = (bestB == kNone) && !(tiA > max(tiX, tiB));
+                }
+            }
+            bool passA = false, passB = false;
+            if (needA || needB)
+            {
+                const float c = s_row[yb - lo];
+                const float rb = rp.rv[oX + b];
+                const float hc = 1.0f - (c * c);
+                if (needA)
+                {
+                    ntests++;
+                    passA = level1_decide<VALIDATE>(1.0f - (rb * rb), ra - (rb * c), hc, th, t2, use_filter, viol);
+                }
+                if (needB)
+                {
+                    ntests++;
+                    passB = level1_decide<VALIDATE>(h00b, rb - (ra * c), hc, th, t2, use_filter, viol);
+                }
+            }
+            if constexpr (MODE == 0)
+            {
+                // fire-and-forget minima: nobody waits for the L2 round trip; which slots got a separating
+                // set is counted once afterwards (level1_count_kernel)
+                if (passB)
+                    (void)__hip_atomic_fetch_min(&p.best[oX + b], (unsigned long long)a, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+                // the lowest passing S = yb for Y = ya within this wave step: one atomic for the wave
+                const unsigned long long pa = __ballot(passA);
+                if (pa != 0ull)
+                {
+                    const unsigned long long bmin = (unsigned long long)(b0 + (__ffsll((long long)pa) - 1));
+                    if (lane == 0)
+                        (void)__hip_atomic_fetch_min(&p.best[oX + a], bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    bestA = min(bestA, bmin);
+                }
+            }
+            else
+            {
+                if (passB)
+                {
+                    // edge X - yb goes: mark both directed slots, clear both bits
+                    p.best[oX + b] = 0ull;
+                    p.best[p.off[yb] + rp.meta[oX + b].y] = 0ull;
+                    if (clear_edge(p.adj, p.deg, p.words, X, yb)) nrem++;
+                }
+                if (__ballot(passA) != 0ull)
+                {
+                    if (lane == 0)
+                    {
+                        p.best[oX + a] = 0ull;
+                        p.best[o0 + k] = 0ull;
+                        if (clear_edge(p.adj, p.deg, p.words, X, ya)) nrem++;
+                    }
+                    bestA = 0ull;
+                }
+            }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);
+        nrem += __shfl_xor(nrem, o);
+        if (VALIDATE) viol += __shfl_xor(viol, o);
+    }
+    if (lane == 0)
+    {
+        if (ntests) atomicAdd(&s_cnt[0], ntests);
+        if (nrem) atomicAdd(&s_cnt[2], nrem);
+        if (VALIDATE && viol) atomicAdd(&s_cnt[3], viol);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&sl[3], s_cnt[3]);
+    }
+}
+
+// rowfound[row] = number of CSR slots of the row that received a separating set; their total is the level's
+// count of removed directed edges
+__global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict__ off, const unsigned long long *__restrict__ best,
+                                                           int *rowfound, int n, unsigned long long *slots)
+{
+    __shared__ int s_sum[4];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int c = 0;
+    if (row < n)
+    {
+        const int o0 = off[row], d = off[row + 1] - o0;
+        for (int k = lane; k < d; k += 64) c += (best[o0 + k] != kNone) ? 1 : 0;
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0)
+    {
+        if (row < n) rowfound[row] = c;
+        s_sum[threadIdx.x >> 6] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        if (t) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+    }
+}
+
+hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
+                              hipStream_t st)
+{
+    const int n = p.n;
+    hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, rv,
+                       static_cast<int4 *>(meta), n);
+    RowsParams rp;
+    rp.rv = rv;
+    rp.meta = static_cast<const int4 *>(meta);
+    rp.panel_cols = std::min(n, 14 * 1024);  // <= 56 KB of LDS per workgroup
+    rp.use_filter = use_filter ? 1 : 0;
+    const int panels = (n + rp.panel_cols - 1) / rp.panel_cols;
+    const size_t lds = sizeof(float) * (size_t)rp.panel_cols;
+    const dim3 grid((unsigned)n, (unsigned)panels);
+    const dim3 blk(kRowsThreads);
+    if (mode == 0 && !validate)
+        hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, lds, st, p, rp);
+    else if (mode == 0)
+        hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, lds, st, p, rp);
+    else if (!validate)
+        hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, lds, st, p, rp);
+    else
+        hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, lds, st, p, rp);
+    if (mode == 0)
+        hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.best, p.rowfound, n, p.slots);
     return hipGetLastError();
 }
 

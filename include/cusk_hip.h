@@ -111,8 +111,9 @@ void cusk_engine_destroy(cusk_engine *e);
 const char *cusk_last_error(const cusk_engine *e);
 /* options: "fast" (default 1: register-Cholesky filter + exact recheck for levels >= 2; 0: exact
  * arithmetic for every test), "validate" (default 0; 1: also run the exact path on every certified
- * verdict and count contradictions in cusk_stats.violations), "pair" (default 1: level-1 pair kernel on symmetric
- * matrices; 0: generic staged kernel), "vec" (default 1: vectorised
+ * verdict and count contradictions in cusk_stats.violations), "pair" (default 1: level-1 kernels that exploit a
+ * symmetric matrix; 0: generic staged kernel), "rows" (default 1: the row-streaming level-1 kernel that reads C
+ * exactly once; 0: the pair-gather kernel), "vec" (default 1: vectorised
  * four-tests-per-ds_read_b128 sweep kernel; 0: scalar fast kernel), "overlap" (default 1: independent degree
  * classes and the winners' exact z run on an auxiliary stream), "corr_popcount" (default 0: int8 MFMA contingency GEMM in
  * cusk_corr_build; 1: bit-plane AND/popcount cross-check kernel), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
