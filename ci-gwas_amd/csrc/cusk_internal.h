@@ -74,6 +74,7 @@ struct cusk_engine
     cusk::DevBuf off[2], nbr[2], best[2], rowinfo[2], rowfound[2], recoff[2];
     cusk::DevBuf items[2][cusk::kNumClasses];
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
+    long long rec_cap = 0;  // records allocated (= directed edges after level 0); rec_s is member-major with this stride
     cusk::DevBuf rv, rpos;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors

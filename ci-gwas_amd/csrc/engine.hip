@@ -69,6 +69,13 @@ struct RunArgs
     int maxlevel;
 };
 
+// layout of the per-run control block (device) and of its pinned mirror (host)
+constexpr size_t kCtlCnt = 0;
+constexpr size_t kCtlSlots = (kCtlCnt + sizeof(LevelCounters) * kLevels + 15) & ~(size_t)15;
+constexpr size_t kCtlRecBase = (kCtlSlots + sizeof(unsigned long long) * kLevels * kCounterSlots * 4 + 15) & ~(size_t)15;
+constexpr size_t kCtlSym = (kCtlRecBase + sizeof(long long) * (kLevels + 1) + 15) & ~(size_t)15;
+constexpr size_t kCtlBytes = kCtlSym + 16;
+
 struct LevelPlan
 {
     SweepParams sp;
@@ -100,10 +107,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     CUSK_HIP(e, e->adj.ensure(bm));
     if (a.mode == 0) CUSK_HIP(e, e->adj0.ensure(bm));
     CUSK_HIP(e, e->deg.ensure(sizeof(int) * (size_t)n));
-    CUSK_HIP(e, e->counters.ensure(sizeof(LevelCounters) * kLevels));
-    CUSK_HIP(e, e->slots.ensure(sizeof(unsigned long long) * kLevels * kCounterSlots * 4));
-    CUSK_HIP(e, e->rec_base.ensure(sizeof(long long) * (kLevels + 1)));
-    CUSK_HIP(e, e->symflag.ensure(sizeof(int)));
+    // per-run control block (level counters, counter slots, record bases, symmetry flag): one allocation, one
+    // memset, one read-back at the end (pinned mirror with the same layout)
+    const size_t ctl_cnt = kCtlCnt, ctl_slots = kCtlSlots, ctl_recbase = kCtlRecBase, ctl_sym = kCtlSym;
+    const size_t ctl_bytes = kCtlBytes;
+    CUSK_HIP(e, e->counters.ensure(ctl_bytes));
     for (int k = 0; k < 2; k++)
     {
         CUSK_HIP(e, e->off[k].ensure(sizeof(int) * ((size_t)n + 1)));
@@ -111,13 +119,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         CUSK_HIP(e, e->rowfound[k].ensure(sizeof(int) * (size_t)n));
         CUSK_HIP(e, e->recoff[k].ensure(sizeof(int) * (size_t)n));
     }
-    LevelCounters *dcnt = e->counters.as<LevelCounters>();
-    unsigned long long *dslots = e->slots.as<unsigned long long>();
-    long long *drec_base = e->rec_base.as<long long>();
-    CUSK_HIP(e, hipMemsetAsync(dcnt, 0, sizeof(LevelCounters) * kLevels, s));
-    CUSK_HIP(e, hipMemsetAsync(dslots, 0, sizeof(unsigned long long) * kLevels * kCounterSlots * 4, s));
-    CUSK_HIP(e, hipMemsetAsync(drec_base, 0, sizeof(long long) * (kLevels + 1), s));
-    CUSK_HIP(e, hipMemsetAsync(e->symflag.p, 0, sizeof(int), s));
+    char *ctl = e->counters.as<char>();
+    LevelCounters *dcnt = reinterpret_cast<LevelCounters *>(ctl + ctl_cnt);
+    unsigned long long *dslots = reinterpret_cast<unsigned long long *>(ctl + ctl_slots);
+    long long *drec_base = reinterpret_cast<long long *>(ctl + ctl_recbase);
+    int *dsym = reinterpret_cast<int *>(ctl + ctl_sym);
+    CUSK_HIP(e, hipMemsetAsync(ctl, 0, ctl_bytes, s));
     if (a.mode == 1)
     {
         CUSK_HIP(e, e->ti.ensure(sizeof(int) * (size_t)n));
@@ -134,7 +141,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         float th0 = a.Th[0];
         if (a.mode == 1 && !het) th0 = (float)((double)a.Th[0] / std::sqrt((double)a.ess_uniform - 3.0));
         CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
-                                  e->opt_assume_symmetric ? nullptr : e->symflag.as<int>(), s));
+                                  e->opt_assume_symmetric ? nullptr : dsym, s));
         if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
     }
     CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
@@ -236,7 +243,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (l == 1 && !rebuilt)
             {
                 // sizes of the CSR arrays and of the binomial table come from the level-1 degrees
-                CUSK_HIP(e, hipMemcpyAsync(e->hflag, e->symflag.p, sizeof(int), hipMemcpyDeviceToHost, s));
+                CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
                 int rc = sync_counters();
                 if (rc != CUSK_OK) return rc;
                 symmetric = (*e->hflag == 0) || (e->opt_assume_symmetric != 0);
@@ -258,8 +265,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     CUSK_HIP(e, e->rec_z.ensure(sizeof(float) * (size_t)cap_edges));
                     CUSK_HIP(e, e->rec_s.ensure(sizeof(int) * kML * (size_t)cap_edges));
                 }
-                if (a.mode == 0)
-                    CUSK_HIP(e, hipMemsetAsync(e->rec_s.p, 0xFF, sizeof(int) * kML * (size_t)cap_edges, s));
+                e->rec_cap = cap_edges;
                 // binomial table C(a, b), a <= max degree: kept on the device across runs
                 if ((long long)maxdeg1 >= e->binom_rows)
                 {
@@ -388,7 +394,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         fp.rec_y = e->rec_y.as<int>();
         fp.rec_l = e->rec_l.as<int>();
         fp.rec_s = e->rec_s.as<int>();
+        fp.rec_cap = e->rec_cap;
         fp.rec_z = e->rec_z.as<float>();
+        fp.meta = pl.use_rows ? e->rpos.as<int4>() : nullptr;
 
         CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
         int rc = launch_level_sweeps(l, false);
@@ -406,17 +414,14 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     {
         CUSK_HIP(e, hipEventRecord(e->ev_join, e->stream2));
         CUSK_HIP(e, hipStreamWaitEvent(s, e->ev_join, 0));
-        int rc = sync_counters();
-        if (rc != CUSK_OK) return rc;
+        // counters, slots and record bases in one copy (hcnt, hslots, hrec_base point into the pinned mirror)
+        CUSK_HIP(e, hipMemcpyAsync(e->hcnt, ctl, ctl_sym, hipMemcpyDeviceToHost, s));
+        CUSK_HIP(e, hipEventRecord(e->ev_run[1], s));
+        CUSK_HIP(e, hipStreamSynchronize(s));
         const int redo = redo_if_overflowed(levels_swept);
         if (redo < 0) return -redo;
         if (redo == 0) break;
     }
-    CUSK_HIP(e, hipMemcpyAsync(e->hslots, dslots, sizeof(unsigned long long) * kLevels * kCounterSlots * 4,
-                               hipMemcpyDeviceToHost, s));
-    CUSK_HIP(e, hipMemcpyAsync(e->hrec_base, drec_base, sizeof(long long) * (kLevels + 1), hipMemcpyDeviceToHost, s));
-    CUSK_HIP(e, hipEventRecord(e->ev_run[1], s));
-    CUSK_HIP(e, hipStreamSynchronize(s));
     float ms = 0.0f;
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[0], e->ev_l1[0]));
     local.kernel_ms[0] = local.level_ms[0] = ms;
@@ -483,10 +488,16 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hcnt), sizeof(LevelCounters) * kLevels) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hslots),
-                             sizeof(unsigned long long) * kLevels * kCounterSlots * 4) == hipSuccess;
-    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hrec_base), sizeof(long long) * (kLevels + 1)) == hipSuccess;
+    {
+        char *hctl = nullptr;
+        ok = ok && hipHostMalloc(reinterpret_cast<void **>(&hctl), kCtlBytes) == hipSuccess;
+        if (ok)
+        {
+            e->hcnt = reinterpret_cast<LevelCounters *>(hctl + kCtlCnt);
+            e->hslots = reinterpret_cast<unsigned long long *>(hctl + kCtlSlots);
+            e->hrec_base = reinterpret_cast<long long *>(hctl + kCtlRecBase);
+        }
+    }
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;
     for (auto &ev : e->ev_run) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (auto &ev : e->ev_corr) ok = ok && hipEventCreate(&ev) == hipSuccess;
@@ -509,8 +520,8 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->slots, &e->rec_base, &e->ti, &e->queue,
-                      &e->symflag, &e->rv, &e->rpos, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+    for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
+                      &e->rv, &e->rpos, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)
@@ -519,8 +530,6 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
         for (auto &b : e->items[k]) b.release();
     }
     if (e->hcnt) (void)hipHostFree(e->hcnt);
-    if (e->hslots) (void)hipHostFree(e->hslots);
-    if (e->hrec_base) (void)hipHostFree(e->hrec_base);
     if (e->hflag) (void)hipHostFree(e->hflag);
     for (auto &ev : e->ev_run)
         if (ev) (void)hipEventDestroy(ev);
@@ -651,6 +660,20 @@ extern "C" int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_
     return CUSK_OK;
 }
 
+// separating sets of all records in the ABI's [nrec x 14] layout
+static int records_to_host(cusk_engine *e, int *S_host)
+{
+    int *tmp = nullptr;
+    const size_t bytes = sizeof(int) * kML * (size_t)e->nrec;
+    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
+    hipError_t st = launch_expand_records(e->rec_s.as<int>(), e->rec_l.as<int>(), e->rec_cap, e->nrec, tmp, e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(S_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    (void)hipFree(tmp);
+    if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    return CUSK_OK;
+}
+
 extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
 {
     if (!e || !e->have_result || e->mode != 0) return fail(e, CUSK_ERR_STATE, "no Skeleton result");
@@ -663,7 +686,8 @@ extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
         std::vector<int> x(e->nrec), y(e->nrec), S((size_t)e->nrec * kML);
         CUSK_HIP(e, hipMemcpy(x.data(), e->rec_x.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
         CUSK_HIP(e, hipMemcpy(y.data(), e->rec_y.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
-        CUSK_HIP(e, hipMemcpy(S.data(), e->rec_s.p, sizeof(int) * kML * e->nrec, hipMemcpyDeviceToHost));
+        int rc = records_to_host(e, S.data());
+        if (rc != CUSK_OK) return rc;
         for (long long r = 0; r < e->nrec; r++)
             std::memcpy(SepSet_host + ((size_t)x[r] * e->n + y[r]) * kML, S.data() + (size_t)r * kML, sizeof(int) * kML);
     }
@@ -681,7 +705,7 @@ extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *le
         if (y && hipMemcpy(y, e->rec_y.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (level && hipMemcpy(level, e->rec_l.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (z && hipMemcpy(z, e->rec_z.p, sizeof(float) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (S && hipMemcpy(S, e->rec_s.p, sizeof(int) * kML * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (S && records_to_host(e, S) != CUSK_OK) return -1;
     }
     return c;
 }

@@ -73,8 +73,10 @@ struct FinalizeParams
     int *deg;
     int words;
     const unsigned long long *binom;
-    int *rec_x, *rec_y, *rec_l, *rec_s;
+    int *rec_x, *rec_y, *rec_l, *rec_s;  // rec_s is member-major: member a of record r at rec_s[a * rec_cap + r]
+    long long rec_cap;
     float *rec_z;
+    const int4 *meta;  // level 1 (row-streaming kernel ran): per CSR slot {Y, position of X in Y's list, off[Y], deg[Y]}
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -111,6 +113,11 @@ __device__ __forceinline__ void unrank_comb(unsigned long long rem, int d, const
 #pragma unroll
     for (int i = 0; i < L; i++)
     {
+        if (i == L - 1)
+        {  // C(., 0) = 1: the last member follows without a search
+            idx[i] = c + (int)rem;
+            break;
+        }
         while (true)
         {
             unsigned long long b = binom[(size_t)(d - 1 - c) * kBinomStride + (L - 1 - i)];
@@ -156,6 +163,8 @@ hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *n
                            int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
+hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
+                                 hipStream_t st);
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,

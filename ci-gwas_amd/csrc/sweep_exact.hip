@@ -232,7 +232,7 @@ hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipSt
 //  gather_records_kernel (one wave per row, no heavy arithmetic): the record index is
 //    rec_base[level] + recoff[row] + (number of earlier selected slots of the row), so records
 //    are ordered by (level, X, position of Y) without atomics; writes x, y, level and the L
-//    members of S (rec_s is pre-filled with -1) and clears the edge in both directions.
+//    members of S (member-major, so a level writes L dense streams) and clears the edge in both directions.
 //  record_z_kernel<L> (one lane per record of this level, count read on the device): the
 //    winner's Fisher z recomputed on the exact path, so pMax never depends on which lane won.
 // ---------------------------------------------------------------------------
@@ -256,7 +256,12 @@ __global__ void gather_records_kernel(FinalizeParams p)
         // touches its own row of the bitmap and its own degree, so no returning atomics are needed:
         // the other side's verdict is looked up (position of `row` in Y's ascending list).
         bool gone = (r != kNone);
-        if (valid && !gone)
+        if (valid && !gone && p.meta != nullptr)
+        {
+            const int4 m = p.meta[o0 + k];
+            gone = (p.best[m.z + m.y] != kNone);
+        }
+        else if (valid && !gone)
         {
             const int oy = p.off[Y];
             int lo = 0, hi = p.off[Y + 1] - oy;
@@ -270,7 +275,21 @@ __global__ void gather_records_kernel(FinalizeParams p)
             }
             gone = (p.best[oy + lo] != kNone);  // adjacency is symmetric at level start: nbr[oy+lo] == row
         }
-        if (gone) atomicAnd(&p.adj[(size_t)row * p.words + (Y >> 6)], ~(1ull << (Y & 63)));
+        // clear the bits: the wave owns this bitmap row, and the Y of a list ascend, so the lanes that share a
+        // 64-bit word are contiguous -> segmented OR over the wave, one plain read-modify-write per word
+        {
+            const int w = valid ? (Y >> 6) : -1 - lane;
+            unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const unsigned long long ob = __shfl_down(bits, o);
+                const int ow = __shfl_down(w, o);
+                if (lane + o < 64 && ow == w) bits |= ob;
+            }
+            const int pw = __shfl_up(w, 1);
+            if (valid && bits != 0ull && (lane == 0 || pw != w)) p.adj[(size_t)row * p.words + w] &= ~bits;
+        }
         removed += __popcll(__ballot(gone));
         const unsigned long long has = __ballot(r != kNone);
         if (has == 0ull) continue;
@@ -283,7 +302,7 @@ __global__ void gather_records_kernel(FinalizeParams p)
         p.rec_y[slot] = Y;
         p.rec_l[slot] = L;
 #pragma unroll
-        for (int a = 0; a < L; a++) p.rec_s[slot * kML + a] = p.nbr[o0 + idx[a]];
+        for (int a = 0; a < L; a++) p.rec_s[(size_t)a * p.rec_cap + slot] = p.nbr[o0 + idx[a]];
     }
     if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
 }
@@ -300,7 +319,7 @@ __global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams 
         const int X = p.rec_x[slot], Y = p.rec_y[slot];
         int S[L];
 #pragma unroll
-        for (int a = 0; a < L; a++) S[a] = p.rec_s[slot * kML + a];
+        for (int a = 0; a < L; a++) S[a] = p.rec_s[(size_t)a * p.rec_cap + slot];
         float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
 #pragma unroll
         for (int a = 0; a < L; a++)
@@ -324,6 +343,27 @@ __global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams 
         (void)z_below<L == 1>(rho, 0.0f, &z);
         p.rec_z[slot] = z;
     }
+}
+
+// records -> the ABI's [count x 14] layout, -1 beyond each record's level (result read-out, not on the hot path)
+__global__ void expand_records_kernel(const int *__restrict__ rec_s, const int *__restrict__ rec_l, long long rec_cap,
+                                      long long count, int *out)
+{
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count * kML) return;
+    const long long r = i / kML;
+    const int a = (int)(i - r * kML);
+    out[i] = (a < rec_l[r]) ? rec_s[(size_t)a * rec_cap + r] : -1;
+}
+
+hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
+                                 hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    const long long total = count * kML;
+    hipLaunchKernelGGL(expand_records_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, rec_s, rec_l, rec_cap,
+                       count, out);
+    return hipGetLastError();
 }
 
 hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z)
