@@ -590,13 +590,16 @@ constexpr int kRowsThreads = 1024;  // 16 waves share one staged row: 2 workgrou
 
 // One level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|), decided against th.  The squared form with the
 // guard band of ci_fast.h settles almost every test in a handful of multiplies; the rest (inside
-// the band, |r| > 0.992 operands, NaN) take the reference's operation order.  VALIDATE: both, counted.
+// the band, |r| >= 1 operands, NaN) take the reference's operation order.  VALIDATE: both, counted.
 template <bool VALIDATE>
 __device__ __forceinline__ bool level1_decide(float h00, float h01, float hc, float th, float t2, bool use_filter,
                                               unsigned long long &viol)
 {
     int fast = kUnsure;
-    if (use_filter && h00 >= kCondMin && hc >= kCondMin)
+    // Both forms start from the SAME fp32 h00, h01, hc (identical operations), so unlike the deeper levels no
+    // conditioning margin is needed here: the squared form and the reference's sqrt/divide/log differ by a few
+    // ulp whatever the operands are, as long as they are positive (NaN and <= 0 take the reference's path).
+    if (use_filter && h00 > 0.0f && hc > 0.0f)
     {
         const float lhs = h01 * h01;
         const float rhs = t2 * (h00 * hc);
@@ -612,10 +615,22 @@ __device__ __forceinline__ bool level1_decide(float h00, float h01, float hc, fl
     return ex;
 }
 
+constexpr int kRowsChunk = kRowsThreads;  // neighbours X of the row handled per staging round
+
+// Work of a row: for every neighbour X (list position a of the row inside X's list) the segment of later
+// positions b in (a, deg X).  The segments of one staging round are laid end to end (block scan, empty ones
+// dropped) and every wave takes a contiguous 1/16 of that flat range, 64 entries per step, so lanes stay busy
+// whatever the segment lengths are; a lane finds its segment by walking the LDS prefix array from the wave's
+// current segment.  Per step and lane: three coalesced loads (nbr, rv, best of X at b), two broadcast loads
+// (rv, best of X at a), one LDS read (C[row, yb]), the filter, and fire-and-forget minima.
 template <int MODE, bool VALIDATE>
-__global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) level1_rows_kernel(SweepParams p, RowsParams rp)
+__global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) level1_rows_kernel(
+    SweepParams p, RowsParams rp)
 {
     extern __shared__ __attribute__((aligned(16))) float s_row[];
+    __shared__ int4 s_meta[kRowsChunk];
+    __shared__ int s_pre[kRowsChunk + 1];
+    __shared__ int s_wtot[2][kRowsThreads / 64];
     __shared__ unsigned long long s_cnt[4];
     const int ya = blockIdx.x;
     const int n = p.n;
@@ -628,71 +643,125 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
     constexpr int kWaves = kRowsThreads >> 6;
     if (tid < 4) s_cnt[tid] = 0ull;
     int4 m = make_int4(0, 0, 0, 0);
-    if (wave < d) m = rp.meta[o0 + wave];
+    if (tid < d) m = rp.meta[o0 + tid];
     {
         const float *src = p.C + (size_t)ya * n;
         for (int j = lo + tid; j < pe; j += kRowsThreads) s_row[j - lo] = src[j];
     }
-    __syncthreads();
     [[maybe_unused]] int tiA = 0;
     if constexpr (MODE == 1) tiA = p.time_index[ya];
     const bool use_filter = rp.use_filter != 0;
     const float th = p.th, t2 = p.t2;
     unsigned long long ntests = 0, nrem = 0, viol = 0;
-    for (int k = wave; k < d; k += kWaves)
+    for (int kc = 0; kc < d; kc += kRowsChunk)
     {
-        const int X = m.x, a = m.y, oX = m.z, dX = m.w;
-        if (k + kWaves < d) m = rp.meta[o0 + k + kWaves];  // next X of this wave: in flight during this one
-        if (a + 1 >= dX) continue;
-        // the last neighbour of X that can lie inside this panel bounds the scan; lists ascend
-        const float ra = rp.rv[oX + a];
-        const float h00b = 1.0f - (ra * ra);
-        [[maybe_unused]] int tiX = 0;
-        if constexpr (MODE == 1) tiX = p.time_index[X];
-        unsigned long long bestA = p.best[oX + a];
-        for (int b0 = a + 1; b0 < dX; b0 += 64)
+        // ---- lay the non-empty segments of this round end to end ----
+        const int len = (kc + tid < d) ? max(0, m.w - m.y - 1) : 0;
+        int pos = (len > 0) ? 1 : 0, pre = len;
+        for (int o = 1; o < 64; o <<= 1)
         {
-            const int b = b0 + lane;
-            bool act = b < dX;
-            int yb = 0;
-            if (act)
+            const int v1 = __shfl_up(pos, o), v2 = __shfl_up(pre, o);
+            if (lane >= o)
             {
-                yb = p.nbr[oX + b];
-                act = (yb >= lo) && (yb < pe);
+                pos += v1;
+                pre += v2;
             }
-            bool needA = false, needB = false;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
-            if (act)
+        }
+        if (kc > 0) __syncthreads();  // the previous round's readers are done with s_meta / s_pre / s_wtot
+        if (lane == 63)
+        {
+            s_wtot[0][wave] = pos;
+            s_wtot[1][wave] = pre;
+        }
+        __syncthreads();
+        int nseg = 0, total = 0, pos0 = 0, pre0 = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++)
+        {
+            const int c1 = s_wtot[0][w], c2 = s_wtot[1][w];
+            if (w < wave)
             {
-                const unsigned long long bestB = p.best[oX + b];
-                if constexpr (MODE == 0)
-                {
-                    needA = bestA >= (unsigned long long)b;
-                    needB = bestB >= (unsigned long long)a;
-                }
+                pos0 += c1;
+                pre0 += c2;
+            }
+            nseg += c1;
+            total += c2;
+        }
+        if (len > 0)
+        {
+            s_meta[pos0 + pos - 1] = m;
+            s_pre[pos0 + pos - 1] = pre0 + pre - len;
+        }
+        if (tid == 0) s_pre[nseg] = total;
+        if (kc + kRowsChunk + tid < d) m = rp.meta[o0 + kc + kRowsChunk + tid];  // next round, in flight meanwhile
+        __syncthreads();
+        // ---- this wave's contiguous share of the flat range ----
+        const int per = ((total + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+        const int f_begin = wave * per, f_end = min(total, f_begin + per);
+        if (f_begin >= f_end) continue;
+        int kw = 0;
+        {
+            int hi = nseg;  // largest kw with s_pre[kw] <= f_begin
+            while (hi - kw > 1)
+            {
+                const int mid = (kw + hi) >> 1;
+                if (s_pre[mid] <= f_begin)
+                    kw = mid;
                 else
-                {
-                    const int tiB = p.time_index[yb];
-                    needA = (bestA == kNone) && !(tiB > max(tiX, tiA));
-                    needB = (bestB == kNone) && !(tiA > max(tiX, tiB));
-                }
+                    hi = mid;
             }
-            bool passA = false, passB = false;
-            if (needA || needB)
+        }
+        for (int base = f_begin; base < f_end; base += 64)
+        {
+            const int f = base + lane;
+            const bool in = f < f_end;
+            int kk = kw;
+            if (in)
+                while (s_pre[kk + 1] <= f) kk++;
+            kw = __shfl(kk, 63);
+            const int seg0 = s_pre[kk];
+            const int4 mm = s_meta[kk];
+            const int X = mm.x, a = mm.y, oX = mm.z;
+            const int b = a + 1 + (f - seg0);
+            // every operand of the step is requested at once (idle lanes re-read slot a): one memory round trip
+            const int ia = oX + a, ib = in ? oX + b : ia;
+            const int yb = p.nbr[ib];
+            const unsigned long long bestB = p.best[ib];
+            const float rb = rp.rv[ib];
+            const unsigned long long bestA = p.best[ia];
+            const float ra = rp.rv[ia];
+            const bool act = in && (yb >= lo) && (yb < pe);
+            const float c = s_row[act ? yb - lo : 0];
+            bool needA, needB;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
+            if constexpr (MODE == 0)
             {
-                const float c = s_row[yb - lo];
-                const float rb = rp.rv[oX + b];
-                const float hc = 1.0f - (c * c);
-                if (needA)
-                {
-                    ntests++;
-                    passA = level1_decide<VALIDATE>(1.0f - (rb * rb), ra - (rb * c), hc, th, t2, use_filter, viol);
-                }
-                if (needB)
-                {
-                    ntests++;
-                    passB = level1_decide<VALIDATE>(h00b, rb - (ra * c), hc, th, t2, use_filter, viol);
-                }
+                needA = act && bestA >= (unsigned long long)b;
+                needB = act && bestB >= (unsigned long long)a;
             }
+            else
+            {
+                const int tiX = p.time_index[X], tiB = p.time_index[yb];
+                needA = act && (bestA == kNone) && !(tiB > max(tiX, tiA));
+                needB = act && (bestB == kNone) && !(tiA > max(tiX, tiB));
+            }
+            const float hc = 1.0f - (c * c);
+            bool passA = false, passB = false;
+            if (needA)
+            {
+                ntests++;
+                passA = level1_decide<VALIDATE>(1.0f - (rb * rb), ra - (rb * c), hc, th, t2, use_filter, viol);
+            }
+            if (needB)
+            {
+                ntests++;
+                passB = level1_decide<VALIDATE>(1.0f - (ra * ra), rb - (ra * c), hc, th, t2, use_filter, viol);
+            }
+            // Y = ya: positions ascend with the lane inside a segment, so the lowest passing lane of a segment
+            // carries the segment's minimum; only that lane speaks
+            const unsigned long long pa = __ballot(passA);
+            const int first_lane = max(0, seg0 - base);
+            const unsigned long long below = pa & ((1ull << lane) - 1ull) & ~((1ull << first_lane) - 1ull);
+            const bool headA = passA && (below == 0ull);
             if constexpr (MODE == 0)
             {
                 // fire-and-forget minima: nobody waits for the L2 round trip; which slots got a separating
@@ -700,15 +769,9 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
                 if (passB)
                     (void)__hip_atomic_fetch_min(&p.best[oX + b], (unsigned long long)a, __ATOMIC_RELAXED,
                                                  __HIP_MEMORY_SCOPE_AGENT);
-                // the lowest passing S = yb for Y = ya within this wave step: one atomic for the wave
-                const unsigned long long pa = __ballot(passA);
-                if (pa != 0ull)
-                {
-                    const unsigned long long bmin = (unsigned long long)(b0 + (__ffsll((long long)pa) - 1));
-                    if (lane == 0)
-                        (void)__hip_atomic_fetch_min(&p.best[oX + a], bmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    bestA = min(bestA, bmin);
-                }
+                if (headA)
+                    (void)__hip_atomic_fetch_min(&p.best[oX + a], (unsigned long long)b, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
             }
             else
             {
@@ -719,15 +782,11 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
                     p.best[p.off[yb] + rp.meta[oX + b].y] = 0ull;
                     if (clear_edge(p.adj, p.deg, p.words, X, yb)) nrem++;
                 }
-                if (__ballot(passA) != 0ull)
+                if (headA)
                 {
-                    if (lane == 0)
-                    {
-                        p.best[oX + a] = 0ull;
-                        p.best[o0 + k] = 0ull;
-                        if (clear_edge(p.adj, p.deg, p.words, X, ya)) nrem++;
-                    }
-                    bestA = 0ull;
+                    p.best[oX + a] = 0ull;
+                    p.best[o0 + rp.meta[oX + a].y] = 0ull;
+                    if (clear_edge(p.adj, p.deg, p.words, X, ya)) nrem++;
                 }
             }
         }
