@@ -165,7 +165,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
-                                           e->rpos.p, s));
+                                           e->rpos.p, e->sel.as<unsigned>(), s));
             return CUSK_OK;
         }
         int nonempty = 0;
@@ -252,11 +252,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 for (int k = 0; k < 2; k++)
                 {
                     CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
-                    if (a.mode == 0 || k == 1)  // hetcor uses `best` only as level-1 alive flags (set 1 = level 1)
-                        CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
+                    if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
                 }
                 CUSK_HIP(e, e->rv.ensure(sizeof(float) * (size_t)cap_edges));
                 CUSK_HIP(e, e->rpos.ensure(sizeof(int) * 4 * (size_t)cap_edges));
+                CUSK_HIP(e, e->sel.ensure(sizeof(unsigned) * (size_t)cap_edges));
                 if (a.mode == 0)
                 {
                     CUSK_HIP(e, e->rec_x.ensure(sizeof(int) * (size_t)cap_edges));
@@ -296,7 +296,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (rebuilt)  // item_scan accumulates the class totals with atomics: start from zero again
                 CUSK_HIP(e, hipMemsetAsync(&dcnt[l].class_items[0], 0, sizeof(long long) * kNumClasses, s));
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
-                                        (a.mode == 0 || pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
+                                        (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
                                         a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,
                                         e->binom.as<unsigned long long>(), chunk, staged_classes, pl.use_pair ? 1 : 0,
                                         e->rowinfo[cs].as<RowInfo>(), dcnt + l, s));
@@ -521,7 +521,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
-                      &e->rv, &e->rpos, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+                      &e->rv, &e->rpos, &e->sel, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)

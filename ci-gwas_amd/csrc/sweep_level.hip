@@ -539,21 +539,21 @@ hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t 
 // ---------------------------------------------------------------------------
 // level 1, row-streaming form (symmetric C, single threshold): HBM traffic = C once
 // ---------------------------------------------------------------------------
-// The pair kernel above pays one 64-byte HBM sector for every 4-byte operand C[Y,S].  Here the
-// loop nest is turned inside out: a workgroup owns one ROW ya of C, streams its upper part
-// C[ya, ya+1..n) into LDS with coalesced loads (the whole matrix is read exactly once over
-// the grid), and serves from LDS every level-1 test that needs an element of that row: for each
-// X adjacent to ya and each later neighbour yb of X, the element C[ya,yb] feeds the two tests
-// (X; ya | yb) and (X; yb | ya).  Everything else those tests need is per-edge data that was
-// compacted at level start and is read contiguously: the neighbour list of X, the gathered
-// row values rv = C[X, adj(X)], the selection state `best`, and rpos (position of ya inside
-// X's list).  One wave per X, lanes stride over yb.  For matrices wider than the LDS panel
-// the columns are processed in panels (blockIdx.y).
+// The pair kernel above pays one 64-byte HBM sector for every 4-byte operand C[Y,S].  Here the loop nest is
+// turned inside out: a workgroup owns one ROW ya of C, stages the parts of C[ya, ya+1..n) that the tests touch
+// (the window behind the diagonal where LD keeps the neighbours, and the trait columns at the end) with coalesced
+// loads, and serves from LDS every level-1 test that needs an element of that row: for each X adjacent to ya and
+// each later neighbour yb of X, the element C[ya,yb] feeds the two tests (X; ya | yb) and (X; yb | ya).
+// Everything else those tests need is per-edge data that was compacted at level start and is read contiguously:
+// the neighbour list of X, the gathered row values rv = C[X, adj(X)], the selection state sel, and meta (position
+// of ya inside X's list).
 
 // Per CSR slot (row, k) with Y = nbr_k:  rv = C[row, Y];  meta = {Y, position of row inside Y's ascending
-// list, start of Y's list, degree of Y}: everything a wave needs to start on one X of its row with one load.
+// list, start of Y's list, degree of Y};  sel = kNone32 (no separating set yet).
+constexpr unsigned kNone32 = 0xffffffffu;
+
 __global__ void level1_prep_kernel(const float *__restrict__ C, const int *__restrict__ off, const int *__restrict__ nbr,
-                                   float *rv, int4 *meta, int n)
+                                   float *rv, int4 *meta, unsigned *sel, int n)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -563,6 +563,7 @@ __global__ void level1_prep_kernel(const float *__restrict__ C, const int *__res
     {
         const int y = nbr[o0 + k];
         rv[o0 + k] = C[(size_t)row * n + y];
+        sel[o0 + k] = kNone32;
         const int oy = off[y];
         const int dy = off[y + 1] - oy;
         int lo = 0, hi = dy;
@@ -582,53 +583,59 @@ struct RowsParams
 {
     const float *rv;
     const int4 *meta;
-    int panel_cols;
+    unsigned *sel;   // level-1 selection state per CSR slot: lowest passing position (Skeleton) / 0 = edge gone (hetcor)
     int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
 };
 
-constexpr int kRowsThreads = 1024;  // 16 waves share one staged row: 2 workgroups fill a CU's 32 wave slots
+constexpr int kRowsThreads = 256;
+constexpr int kRowsChunk = 256;    // neighbours X of the row handled per staging round
+constexpr int kRowsNear = 2048;    // staged window C[row, row+1 .. row+1+kRowsNear): where LD keeps the neighbours
+constexpr int kRowsTail = 256;     // staged window C[row, n-kRowsTail .. n): the trait columns close every list
 
-// One level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|), decided against th.  The squared form with the
-// guard band of ci_fast.h settles almost every test in a handful of multiplies; the rest (inside
-// the band, |r| >= 1 operands, NaN) take the reference's operation order.  VALIDATE: both, counted.
-template <bool VALIDATE>
-__device__ __forceinline__ bool level1_decide(float h00, float h01, float hc, float th, float t2, bool use_filter,
-                                              unsigned long long &viol)
+// Level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|) against th, in the squared form with the guard band of
+// ci_fast.h.  It starts from the SAME fp32 h00, h01, hc as the reference's form (identical operations), so
+// unlike the deeper levels no conditioning margin is needed: the two differ by a few ulp whatever the
+// operands are, as long as they are positive.  Returns pass; sure = false (inside the band, operand <= 0, NaN,
+// filter off) sends the lane to level1_exact.
+__device__ __forceinline__ bool level1_filter(float h00, float h01, float hc, float t2, bool ok, bool &sure)
 {
-    int fast = kUnsure;
-    // Both forms start from the SAME fp32 h00, h01, hc (identical operations), so unlike the deeper levels no
-    // conditioning margin is needed here: the squared form and the reference's sqrt/divide/log differ by a few
-    // ulp whatever the operands are, as long as they are positive (NaN and <= 0 take the reference's path).
-    if (use_filter && h00 > 0.0f && hc > 0.0f)
-    {
-        const float lhs = h01 * h01;
-        const float rhs = t2 * (h00 * hc);
-        if (lhs < rhs * (1.0f - kBeta))
-            fast = kPass;
-        else if (lhs > rhs * (1.0f + kBeta))
-            fast = kFail;
-    }
-    if (!VALIDATE && fast != kUnsure) return fast == kPass;
-    const float rho = h01 / (sqrtf(fabsf(h00)) * sqrtf(fabsf(hc)));
-    const bool ex = z_below<true>(rho, th);
-    if (VALIDATE && fast != kUnsure && (fast == kPass) != ex) viol++;
-    return ex;
+    const float lhs = h01 * h01;
+    const float rhs = t2 * (h00 * hc);
+    const bool pass = lhs < rhs * (1.0f - kBeta);
+    const bool fail = lhs > rhs * (1.0f + kBeta);
+    sure = ok && (h00 > 0.0f) && (pass || fail);
+    return pass;
 }
 
-constexpr int kRowsChunk = kRowsThreads;  // neighbours X of the row handled per staging round
+__device__ __forceinline__ bool level1_exact(float h00, float h01, float hc, float th)
+{
+    const float rho = h01 / (sqrtf(fabsf(h00)) * sqrtf(fabsf(hc)));
+    return z_below<true>(rho, th);
+}
 
 // Work of a row: for every neighbour X (list position a of the row inside X's list) the segment of later
 // positions b in (a, deg X).  The segments of one staging round are laid end to end (block scan, empty ones
-// dropped) and every wave takes a contiguous 1/16 of that flat range, 64 entries per step, so lanes stay busy
-// whatever the segment lengths are; a lane finds its segment by walking the LDS prefix array from the wave's
-// current segment.  Per step and lane: three coalesced loads (nbr, rv, best of X at b), two broadcast loads
-// (rv, best of X at a), one LDS read (C[row, yb]), the filter, and fire-and-forget minima.
-template <int MODE, bool VALIDATE>
-__global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) level1_rows_kernel(
-    SweepParams p, RowsParams rp)
+// dropped) and every wave takes a contiguous quarter of that flat range, 64 entries per step, so lanes stay
+// busy whatever the segment lengths are; a lane finds its segment by walking the LDS prefix array from the
+// wave's current segment.  Per step and lane: three coalesced loads (nbr, rv, sel of X at b), one broadcast
+// load (sel of X at a), C[row, yb] from the staged windows of the row (a plain load for the few columns
+// outside them), the filter for both tests without branches, and fire-and-forget minima.  The loads of step
+// i+1 are issued before step i is evaluated.
+struct RowsStep
 {
-    extern __shared__ __attribute__((aligned(16))) float s_row[];
-    __shared__ int4 s_meta[kRowsChunk];
+    unsigned ia, ib;
+    int a, b, X, first_lane;
+    bool in;
+    int yb;
+    float ra, rb;
+    unsigned selA, selB;
+};
+
+template <int MODE, bool VALIDATE>
+__global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p, RowsParams rp)
+{
+    __shared__ float s_row[kRowsNear + kRowsTail];
+    __shared__ int4 s_seg[kRowsChunk];  // {slot of (X, a), a, C[X, row] bits, X}
     __shared__ int s_pre[kRowsChunk + 1];
     __shared__ int s_wtot[2][kRowsThreads / 64];
     __shared__ unsigned long long s_cnt[4];
@@ -636,23 +643,29 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
     const int n = p.n;
     const int o0 = p.off[ya];
     const int d = p.off[ya + 1] - o0;
-    const int pb = blockIdx.y * rp.panel_cols, pe = min(n, pb + rp.panel_cols);
-    const int lo = max(ya + 1, pb);
-    if (d == 0 || lo >= pe) return;
+    const int lo = ya + 1;
+    if (d == 0 || lo >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kRowsThreads >> 6;
+    const int tail0 = max(0, n - kRowsTail);
     if (tid < 4) s_cnt[tid] = 0ull;
     int4 m = make_int4(0, 0, 0, 0);
-    if (tid < d) m = rp.meta[o0 + tid];
+    float mra = 0.0f;
+    if (tid < d)
     {
-        const float *src = p.C + (size_t)ya * n;
-        for (int j = lo + tid; j < pe; j += kRowsThreads) s_row[j - lo] = src[j];
+        m = rp.meta[o0 + tid];
+        mra = rp.rv[m.z + m.y];  // C[X, row]
+    }
+    const float *crow = p.C + (size_t)ya * n;
+    {
+        for (int j = tid; j < kRowsNear && lo + j < n; j += kRowsThreads) s_row[j] = crow[lo + j];
+        for (int j = tid; j < kRowsTail && tail0 + j < n; j += kRowsThreads) s_row[kRowsNear + j] = crow[tail0 + j];
     }
     [[maybe_unused]] int tiA = 0;
     if constexpr (MODE == 1) tiA = p.time_index[ya];
     const bool use_filter = rp.use_filter != 0;
     const float th = p.th, t2 = p.t2;
-    unsigned long long ntests = 0, nrem = 0, viol = 0;
+    unsigned ntests = 0, nrem = 0, viol = 0;
     for (int kc = 0; kc < d; kc += kRowsChunk)
     {
         // ---- lay the non-empty segments of this round end to end ----
@@ -667,7 +680,7 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
                 pre += v2;
             }
         }
-        if (kc > 0) __syncthreads();  // the previous round's readers are done with s_meta / s_pre / s_wtot
+        if (kc > 0) __syncthreads();  // the previous round's readers are done with s_seg / s_pre / s_wtot
         if (lane == 63)
         {
             s_wtot[0][wave] = pos;
@@ -689,11 +702,15 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
         }
         if (len > 0)
         {
-            s_meta[pos0 + pos - 1] = m;
+            s_seg[pos0 + pos - 1] = make_int4(m.z + m.y, m.y, __float_as_int(mra), m.x);
             s_pre[pos0 + pos - 1] = pre0 + pre - len;
         }
         if (tid == 0) s_pre[nseg] = total;
-        if (kc + kRowsChunk + tid < d) m = rp.meta[o0 + kc + kRowsChunk + tid];  // next round, in flight meanwhile
+        if (kc + kRowsChunk + tid < d)
+        {  // next round, in flight meanwhile
+            m = rp.meta[o0 + kc + kRowsChunk + tid];
+            mra = rp.rv[m.z + m.y];
+        }
         __syncthreads();
         // ---- this wave's contiguous share of the flat range ----
         const int per = ((total + kWaves * 64 - 1) / (kWaves * 64)) * 64;
@@ -711,97 +728,123 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
                     hi = mid;
             }
         }
-        for (int base = f_begin; base < f_end; base += 64)
-        {
+        // locate the lanes of one step inside the segments and request its operands (idle lanes re-read slot a)
+        auto issue = [&](int base, RowsStep &st) {
             const int f = base + lane;
-            const bool in = f < f_end;
+            st.in = f < f_end;
             int kk = kw;
-            if (in)
+            if (st.in)
                 while (s_pre[kk + 1] <= f) kk++;
             kw = __shfl(kk, 63);
             const int seg0 = s_pre[kk];
-            const int4 mm = s_meta[kk];
-            const int X = mm.x, a = mm.y, oX = mm.z;
-            const int b = a + 1 + (f - seg0);
-            // every operand of the step is requested at once (idle lanes re-read slot a): one memory round trip
-            const int ia = oX + a, ib = in ? oX + b : ia;
-            const int yb = p.nbr[ib];
-            const unsigned long long bestB = p.best[ib];
-            const float rb = rp.rv[ib];
-            const unsigned long long bestA = p.best[ia];
-            const float ra = rp.rv[ia];
-            const bool act = in && (yb >= lo) && (yb < pe);
-            const float c = s_row[act ? yb - lo : 0];
+            const int4 e = s_seg[kk];
+            st.a = e.y;
+            st.b = e.y + 1 + (f - seg0);
+            st.ra = __int_as_float(e.z);
+            st.X = e.w;
+            st.first_lane = max(0, seg0 - base);
+            st.ia = (unsigned)e.x;
+            st.ib = st.in ? (unsigned)(e.x + 1 + (f - seg0)) : st.ia;
+            st.yb = p.nbr[st.ib];
+            st.rb = rp.rv[st.ib];
+            st.selB = rp.sel[st.ib];
+            st.selA = rp.sel[st.ia];
+        };
+        RowsStep cur, nxt;
+        issue(f_begin, cur);
+        for (int base = f_begin; base < f_end; base += 64)
+        {
+            const bool more = base + 64 < f_end;
+            if (more) issue(base + 64, nxt);
+            const int yb = cur.yb, a = cur.a, b = cur.b;
+            const float ra = cur.ra, rb = cur.rb;
+            const bool act = cur.in;  // lists ascend: yb > row for every b > a
+            const int j = yb - lo;
+            const bool staged = (j < kRowsNear) || (yb >= tail0);
+            float c = s_row[(act && staged) ? ((j < kRowsNear) ? j : kRowsNear + (yb - tail0)) : 0];
+            if (act && !staged) c = crow[yb];
             bool needA, needB;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
             if constexpr (MODE == 0)
             {
-                needA = act && bestA >= (unsigned long long)b;
-                needB = act && bestB >= (unsigned long long)a;
+                needA = act && cur.selA >= (unsigned)b;
+                needB = act && cur.selB >= (unsigned)a;
             }
             else
             {
-                const int tiX = p.time_index[X], tiB = p.time_index[yb];
-                needA = act && (bestA == kNone) && !(tiB > max(tiX, tiA));
-                needB = act && (bestB == kNone) && !(tiA > max(tiX, tiB));
+                const int tiX = p.time_index[cur.X], tiB = p.time_index[yb];
+                needA = act && (cur.selA == kNone32) && !(tiB > max(tiX, tiA));
+                needB = act && (cur.selB == kNone32) && !(tiA > max(tiX, tiB));
             }
             const float hc = 1.0f - (c * c);
-            bool passA = false, passB = false;
-            if (needA)
-            {
-                ntests++;
-                passA = level1_decide<VALIDATE>(1.0f - (rb * rb), ra - (rb * c), hc, th, t2, use_filter, viol);
+            const float h00a = 1.0f - (rb * rb), h01a = ra - (rb * c);
+            const float h00b = 1.0f - (ra * ra), h01b = rb - (ra * c);
+            const bool ok = use_filter && (hc > 0.0f);
+            bool sureA, sureB;
+            bool passA = level1_filter(h00a, h01a, hc, t2, ok, sureA);
+            bool passB = level1_filter(h00b, h01b, hc, t2, ok, sureB);
+            ntests += (needA ? 1u : 0u) + (needB ? 1u : 0u);
+            const bool slowA = needA && (VALIDATE || !sureA), slowB = needB && (VALIDATE || !sureB);
+            if (__ballot(slowA || slowB) != 0ull)
+            {  // rare: the reference's operation order
+                if (slowA)
+                {
+                    const bool ex = level1_exact(h00a, h01a, hc, th);
+                    if (VALIDATE && sureA && ex != passA) viol++;
+                    passA = ex;
+                }
+                if (slowB)
+                {
+                    const bool ex = level1_exact(h00b, h01b, hc, th);
+                    if (VALIDATE && sureB && ex != passB) viol++;
+                    passB = ex;
+                }
             }
-            if (needB)
-            {
-                ntests++;
-                passB = level1_decide<VALIDATE>(1.0f - (ra * ra), rb - (ra * c), hc, th, t2, use_filter, viol);
-            }
+            passA = passA && needA;
+            passB = passB && needB;
             // Y = ya: positions ascend with the lane inside a segment, so the lowest passing lane of a segment
             // carries the segment's minimum; only that lane speaks
             const unsigned long long pa = __ballot(passA);
-            const int first_lane = max(0, seg0 - base);
-            const unsigned long long below = pa & ((1ull << lane) - 1ull) & ~((1ull << first_lane) - 1ull);
+            const unsigned long long below = pa & ((1ull << lane) - 1ull) & ~((1ull << cur.first_lane) - 1ull);
             const bool headA = passA && (below == 0ull);
             if constexpr (MODE == 0)
             {
                 // fire-and-forget minima: nobody waits for the L2 round trip; which slots got a separating
                 // set is counted once afterwards (level1_count_kernel)
                 if (passB)
-                    (void)__hip_atomic_fetch_min(&p.best[oX + b], (unsigned long long)a, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_min(&rp.sel[cur.ib], (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (headA)
-                    (void)__hip_atomic_fetch_min(&p.best[oX + a], (unsigned long long)b, __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_min(&rp.sel[cur.ia], (unsigned)b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             else
             {
                 if (passB)
                 {
                     // edge X - yb goes: mark both directed slots, clear both bits
-                    p.best[oX + b] = 0ull;
-                    p.best[p.off[yb] + rp.meta[oX + b].y] = 0ull;
-                    if (clear_edge(p.adj, p.deg, p.words, X, yb)) nrem++;
+                    rp.sel[cur.ib] = 0u;
+                    rp.sel[p.off[yb] + rp.meta[cur.ib].y] = 0u;
+                    if (clear_edge(p.adj, p.deg, p.words, cur.X, yb)) nrem++;
                 }
                 if (headA)
                 {
-                    p.best[oX + a] = 0ull;
-                    p.best[o0 + rp.meta[oX + a].y] = 0ull;
-                    if (clear_edge(p.adj, p.deg, p.words, X, ya)) nrem++;
+                    rp.sel[cur.ia] = 0u;
+                    rp.sel[o0 + rp.meta[cur.ia].y] = 0u;
+                    if (clear_edge(p.adj, p.deg, p.words, cur.X, ya)) nrem++;
                 }
             }
+            if (more) cur = nxt;
         }
     }
     for (int o = 32; o > 0; o >>= 1)
     {
-        ntests += __shfl_xor(ntests, o);
+        ntests += __shfl_xor(ntests, o);  // < 2^32 per wave: 64 lanes x (work of a quarter row)
         nrem += __shfl_xor(nrem, o);
         if (VALIDATE) viol += __shfl_xor(viol, o);
     }
     if (lane == 0)
     {
-        if (ntests) atomicAdd(&s_cnt[0], ntests);
-        if (nrem) atomicAdd(&s_cnt[2], nrem);
-        if (VALIDATE && viol) atomicAdd(&s_cnt[3], viol);
+        if (ntests) atomicAdd(&s_cnt[0], (unsigned long long)ntests);
+        if (nrem) atomicAdd(&s_cnt[2], (unsigned long long)nrem);
+        if (VALIDATE && viol) atomicAdd(&s_cnt[3], (unsigned long long)viol);
     }
     __syncthreads();
     if (tid == 0)
@@ -813,10 +856,12 @@ __global__ void __launch_bounds__(kRowsThreads) __attribute__((amdgpu_waves_per_
     }
 }
 
-// rowfound[row] = number of CSR slots of the row that received a separating set; their total is the level's
-// count of removed directed edges
-__global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict__ off, const unsigned long long *__restrict__ best,
-                                                           int *rowfound, int n, unsigned long long *slots)
+// Skeleton mode, after the sweep: best = selected position per CSR slot in the engine's 64-bit form, rowfound[row]
+// = number of slots of the row that received a separating set; their total is the level's count of removed
+// directed edges
+__global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict__ off, const unsigned *__restrict__ sel,
+                                                           unsigned long long *best, int *rowfound, int n,
+                                                           unsigned long long *slots)
 {
     __shared__ int s_sum[4];
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -825,7 +870,12 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
     if (row < n)
     {
         const int o0 = off[row], d = off[row + 1] - o0;
-        for (int k = lane; k < d; k += 64) c += (best[o0 + k] != kNone) ? 1 : 0;
+        for (int k = lane; k < d; k += 64)
+        {
+            const unsigned v = sel[o0 + k];
+            best[o0 + k] = (v == kNone32) ? kNone : (unsigned long long)v;
+            c += (v != kNone32) ? 1 : 0;
+        }
     }
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
     if (lane == 0)
@@ -842,30 +892,29 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
 }
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              hipStream_t st)
+                              unsigned *sel, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, rv,
-                       static_cast<int4 *>(meta), n);
+                       static_cast<int4 *>(meta), sel, n);
     RowsParams rp;
     rp.rv = rv;
     rp.meta = static_cast<const int4 *>(meta);
-    rp.panel_cols = std::min(n, 14 * 1024);  // <= 56 KB of LDS per workgroup
+    rp.sel = sel;
     rp.use_filter = use_filter ? 1 : 0;
-    const int panels = (n + rp.panel_cols - 1) / rp.panel_cols;
-    const size_t lds = sizeof(float) * (size_t)rp.panel_cols;
-    const dim3 grid((unsigned)n, (unsigned)panels);
+    const dim3 grid((unsigned)n);
     const dim3 blk(kRowsThreads);
     if (mode == 0 && !validate)
-        hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, lds, st, p, rp);
+        hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, 0, st, p, rp);
     else if (mode == 0)
-        hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, lds, st, p, rp);
+        hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, 0, st, p, rp);
     else if (!validate)
-        hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, lds, st, p, rp);
+        hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, 0, st, p, rp);
     else
-        hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, lds, st, p, rp);
+        hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
     if (mode == 0)
-        hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.best, p.rowfound, n, p.slots);
+        hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
+                           p.slots);
     return hipGetLastError();
 }
 
