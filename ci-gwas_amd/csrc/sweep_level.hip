@@ -3,6 +3,7 @@
 // Replaces /root/reference/cusk/src/cuPC-S.cu:458-484 (cal_Indepl0), :6355-6432 (scan_compact),
 // :486-582 (cal_Indepl1) and their hetcor twins (src/hetcor-cuPC-S.cu:343-486).
 #include <algorithm>
+#include <type_traits>
 
 #include "ci_exact.h"
 #include "ci_fast.h"
@@ -539,11 +540,12 @@ hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t 
 // ---------------------------------------------------------------------------
 // level 1, row-streaming form (symmetric C, single threshold): HBM traffic = C once
 // ---------------------------------------------------------------------------
-// The pair kernel above pays one 64-byte HBM sector for every 4-byte operand C[Y,S].  Here the loop nest is
-// turned inside out: a workgroup owns one ROW ya of C, stages the parts of C[ya, ya+1..n) that the tests touch
-// (the window behind the diagonal where LD keeps the neighbours, and the trait columns at the end) with coalesced
-// loads, and serves from LDS every level-1 test that needs an element of that row: for each X adjacent to ya and
-// each later neighbour yb of X, the element C[ya,yb] feeds the two tests (X; ya | yb) and (X; yb | ya).
+// The pair kernel above pays one 64-byte HBM sector for every 4-byte operand C[Y,S], because a workgroup owns an
+// X and its operands C[ya, yb] are scattered over as many rows as X has neighbours.  Here the loop nest is turned
+// inside out: a workgroup owns one ROW ya of C and runs every level-1 test that needs an element of that row:
+// for each X adjacent to ya and each later neighbour yb of X, the element C[ya,yb] feeds the two tests
+// (X; ya | yb) and (X; yb | ya).  All of the workgroup's reads of C fall into that one row (and, with LD, mostly
+// into a narrow window behind the diagonal), so HBM sees each touched sector once and L1/L2 serve the rest.
 // Everything else those tests need is per-edge data that was compacted at level start and is read contiguously:
 // the neighbour list of X, the gathered row values rv = C[X, adj(X)], the selection state sel, and meta (position
 // of ya inside X's list).
@@ -589,8 +591,6 @@ struct RowsParams
 
 constexpr int kRowsThreads = 256;
 constexpr int kRowsChunk = 256;    // neighbours X of the row handled per staging round
-constexpr int kRowsNear = 2048;    // staged window C[row, row+1 .. row+1+kRowsNear): where LD keeps the neighbours
-constexpr int kRowsTail = 256;     // staged window C[row, n-kRowsTail .. n): the trait columns close every list
 
 // Level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|) against th, in the squared form with the guard band of
 // ci_fast.h.  It starts from the SAME fp32 h00, h01, hc as the reference's form (identical operations), so
@@ -617,24 +617,30 @@ __device__ __forceinline__ bool level1_exact(float h00, float h01, float hc, flo
 // positions b in (a, deg X).  The segments of one staging round are laid end to end (block scan, empty ones
 // dropped) and every wave takes a contiguous quarter of that flat range, 64 entries per step, so lanes stay
 // busy whatever the segment lengths are; a lane finds its segment by walking the LDS prefix array from the
-// wave's current segment.  Per step and lane: three coalesced loads (nbr, rv, sel of X at b), one broadcast
-// load (sel of X at a), C[row, yb] from the staged windows of the row (a plain load for the few columns
-// outside them), the filter for both tests without branches, and fire-and-forget minima.  The loads of step
-// i+1 are issued before step i is evaluated.
+// wave's current segment.  A step is a three-stage software pipeline over three operand sets:
+//   stage A (step i+2): three coalesced loads (nbr, rv, sel of X at b) and one broadcast load (sel of X at a);
+//   stage B (step i+1): C[row, yb] -- consecutive lanes hold ascending, mostly adjacent columns of ONE row of C,
+//                       the row every wave of the workgroup reads, so it is served by L1/L2;
+//   stage C (step i):   both tests through the branch-free filter, fire-and-forget minima.
+template <typename T>
+__device__ __forceinline__ T ld32(const T *base, unsigned idx)
+{
+    return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + (idx << 2));
+}
+
 struct RowsStep
 {
     unsigned ia, ib;
     int a, b, X, first_lane;
     bool in;
     int yb;
-    float ra, rb;
+    float ra, rb, c;
     unsigned selA, selB;
 };
 
 template <int MODE, bool VALIDATE>
 __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p, RowsParams rp)
 {
-    __shared__ float s_row[kRowsNear + kRowsTail];
     __shared__ int4 s_seg[kRowsChunk];  // {slot of (X, a), a, C[X, row] bits, X}
     __shared__ int s_pre[kRowsChunk + 1];
     __shared__ int s_wtot[2][kRowsThreads / 64];
@@ -643,11 +649,9 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     const int n = p.n;
     const int o0 = p.off[ya];
     const int d = p.off[ya + 1] - o0;
-    const int lo = ya + 1;
-    if (d == 0 || lo >= n) return;
+    if (d == 0 || ya + 1 >= n) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kRowsThreads >> 6;
-    const int tail0 = max(0, n - kRowsTail);
     if (tid < 4) s_cnt[tid] = 0ull;
     int4 m = make_int4(0, 0, 0, 0);
     float mra = 0.0f;
@@ -657,10 +661,6 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
         mra = rp.rv[m.z + m.y];  // C[X, row]
     }
     const float *crow = p.C + (size_t)ya * n;
-    {
-        for (int j = tid; j < kRowsNear && lo + j < n; j += kRowsThreads) s_row[j] = crow[lo + j];
-        for (int j = tid; j < kRowsTail && tail0 + j < n; j += kRowsThreads) s_row[kRowsNear + j] = crow[tail0 + j];
-    }
     [[maybe_unused]] int tiA = 0;
     if constexpr (MODE == 1) tiA = p.time_index[ya];
     const bool use_filter = rp.use_filter != 0;
@@ -728,8 +728,10 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
                     hi = mid;
             }
         }
-        // locate the lanes of one step inside the segments and request its operands (idle lanes re-read slot a)
-        auto issue = [&](int base, RowsStep &st) {
+        // stage A: locate the lanes of a step inside the segments and request the per-slot operands.  Lanes past
+        // the end of the wave's range idle on slot a of the last segment, so every request is unconditional (a
+        // conditional one would make the compiler drain ALL outstanding loads at the join).
+        auto stage_a = [&](int base, RowsStep &st) {
             const int f = base + lane;
             st.in = f < f_end;
             int kk = kw;
@@ -745,24 +747,18 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
             st.first_lane = max(0, seg0 - base);
             st.ia = (unsigned)e.x;
             st.ib = st.in ? (unsigned)(e.x + 1 + (f - seg0)) : st.ia;
-            st.yb = p.nbr[st.ib];
-            st.rb = rp.rv[st.ib];
-            st.selB = rp.sel[st.ib];
-            st.selA = rp.sel[st.ia];
+            // 32-bit byte offsets off uniform bases (the CSR arrays stay below 4 GB): scalar-base addressing, no
+            // 64-bit vector address arithmetic
+            st.yb = ld32<int>(p.nbr, st.ib);
+            st.rb = ld32<float>(rp.rv, st.ib);
+            st.selB = ld32<unsigned>(rp.sel, st.ib);
+            st.selA = ld32<unsigned>(rp.sel, st.ia);
         };
-        RowsStep cur, nxt;
-        issue(f_begin, cur);
-        for (int base = f_begin; base < f_end; base += 64)
-        {
-            const bool more = base + 64 < f_end;
-            if (more) issue(base + 64, nxt);
+        auto stage_b = [&](RowsStep &st) { st.c = ld32<float>(crow, (unsigned)st.yb); };
+        auto stage_c = [&](const RowsStep &cur) {
             const int yb = cur.yb, a = cur.a, b = cur.b;
-            const float ra = cur.ra, rb = cur.rb;
-            const bool act = cur.in;  // lists ascend: yb > row for every b > a
-            const int j = yb - lo;
-            const bool staged = (j < kRowsNear) || (yb >= tail0);
-            float c = s_row[(act && staged) ? ((j < kRowsNear) ? j : kRowsNear + (yb - tail0)) : 0];
-            if (act && !staged) c = crow[yb];
+            const float ra = cur.ra, rb = cur.rb, c = cur.c;
+            const bool act = cur.in;
             bool needA, needB;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
             if constexpr (MODE == 0)
             {
@@ -831,7 +827,30 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
                     if (clear_edge(p.adj, p.deg, p.words, cur.X, ya)) nrem++;
                 }
             }
-            if (more) cur = nxt;
+        };
+        // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
+        // the set it needs); the scheduling barriers keep the requests ahead of the evaluation
+        RowsStep s0, s1, s2;
+        stage_a(f_begin, s0);
+        stage_a(f_begin + 64, s1);
+        stage_b(s0);
+        for (int base = f_begin;; base += 192)
+        {
+            stage_a(base + 128, s2);
+            stage_b(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s0);
+            if (base + 64 >= f_end) break;
+            stage_a(base + 192, s0);
+            stage_b(s2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s1);
+            if (base + 128 >= f_end) break;
+            stage_a(base + 256, s1);
+            stage_b(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s2);
+            if (base + 192 >= f_end) break;
         }
     }
     for (int o = 32; o > 0; o >>= 1)
