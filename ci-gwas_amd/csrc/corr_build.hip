@@ -410,81 +410,196 @@ __global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restric
     }
 }
 
-// SNP x trait Pearson, tiled: 16 markers per workgroup, 16 lanes per marker striding the
-// individuals; the traits' values of a 256-individual chunk are staged in LDS once and shared
-// by the 16 markers (the naive kernel above re-reads every trait from L2 for every marker).
-constexpr int kMxpChunk = 256;
-__global__ void __launch_bounds__(256) mxp_tile_kernel(const unsigned char *__restrict__ bed, const float *__restrict__ phen,
-                                                        const float *__restrict__ mean, const float *__restrict__ sd, float *C,
-                                                        float *mxp, size_t m, size_t N, size_t p, size_t clb, size_t n,
-                                                        size_t p0, int pcount)
+// SNP x trait Pearson as an exact-f32 MFMA contraction over individuals (corr_kernels.cu:157-238 gives the
+// formula: r = (sum g y - mean_g sum y) / (n sd_g) over the individuals where genotype and trait are both
+// present).  With A = [genotype dosage | non-missing flag] (markers x individuals, decoded from .bed in
+// registers) and B = [trait, NaN -> 0 | NaN flag] (individuals x traits) the three sums are A_g B_y, A_v B_y and
+// A_v B_nan: v_mfma_f32_32x32x2_f32 accumulates each as a k-ordered chain of f32 FMAs (exact f32, the matrix
+// pipe runs at the f32 vector rate but leaves the vector ALU to the decoding and needs 48 accumulator registers
+// instead of 3 per marker-trait pair).
+//
+// Workgroup = 8 waves, output tile 32 markers x 32 traits; wave w owns the w-th eighth of the individuals
+// (split-K) and the eight partial tiles are added in a fixed order through LDS, so the result is deterministic.
+// Operand lane maps of the 32x32x2 form: lane l holds A[row l&31][k = l>>5] and B[k = l>>5][col l&31], one f32
+// each: lane (i, k) walks marker i and takes individuals 2q+k of each byte (two MFMA steps per .bed byte), lane
+// (j, k) walks trait row j with float4 loads.  The NaN product is only issued for 16-individual groups that
+// contain a NaN.
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kMxpWaves = 8;
+
+// FAST: every marker row of the .bed block is dword-aligned and every trait row 16-byte aligned (N % 4 == 0 and
+// aligned bases, checked by the launcher), so full 16-individual groups are fetched with one dword + four
+// float4 loads, unconditionally, two groups in flight.  Anything else (odd N, the last partial group) goes
+// through the bounds-checked fetch.
+template <bool FAST>
+__global__ void __launch_bounds__(64 * kMxpWaves) mxp_mfma_kernel(const unsigned char *__restrict__ bed,
+                                                                  const float *__restrict__ phen,
+                                                                  const float *__restrict__ mean,
+                                                                  const float *__restrict__ sd, float *C, float *mxp, size_t m,
+                                                                  size_t N, size_t p, size_t clb, size_t n, size_t p0,
+                                                                  int pcount)
 {
-    __shared__ float sy[kMaxPhenRegs][kMxpChunk];
-    const int tid = threadIdx.x, mi = tid >> 4, sl = tid & 15;
-    const size_t mk = (size_t)blockIdx.x * 16 + mi;
-    const bool ok = mk < m;
-    float sgy[kMaxPhenRegs], syv[kMaxPhenRegs], sn[kMaxPhenRegs];
+    __shared__ float s_part[kMxpWaves / 2][3][16][64];  // partial accumulators of the upper half of the waves
+    __shared__ float s_sv[kMxpWaves][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, kh = lane >> 5;
+    const size_t mk = (size_t)blockIdx.x * 32 + r32;  // A side: this lane's marker
+    const bool mok = mk < m;
+    const unsigned char *rowp = bed + (mok ? mk : 0) * clb;
+    const bool tok = r32 < pcount;  // B side: this lane's trait
+    const float *yrow = phen + (p0 + (tok ? r32 : 0)) * N;
+    // Lanes without a marker / trait still feed the MFMA (row i of A only reaches row i of the product, column j
+    // of B only column j, and those are never written); their genotypes are forced to "missing".
+
+    v16f acc_gy, acc_vy, acc_vn;
 #pragma unroll
-    for (int k = 0; k < kMaxPhenRegs; k++) sgy[k] = syv[k] = sn[k] = 0.0f;
-    for (size_t c0 = 0; c0 < N; c0 += kMxpChunk)
-    {
-        __syncthreads();
-        for (int e = tid; e < pcount * kMxpChunk; e += 256)
+    for (int r = 0; r < 16; r++) acc_gy[r] = acc_vy[r] = acc_vn[r] = 0.0f;
+    float sv = 0.0f;
+
+    // bounds-checked operands of group g: individuals at or beyond N count as missing / zero
+    auto fetch_checked = [&](size_t g, unsigned &w, float (&y)[16]) {
+        const size_t s0 = g * 16, off = g * 4;
+        w = 0u;
+        for (size_t bb = 0; bb < 4; bb++) w |= (unsigned)((mok && off + bb < clb) ? rowp[off + bb] : 0x55u) << (8 * bb);
+#pragma unroll
+        for (int q = 0; q < 16; q++)
         {
-            const int t = e / kMxpChunk, s = e - t * kMxpChunk;
-            sy[t][s] = (c0 + s < N) ? phen[(p0 + t) * N + c0 + s] : __builtin_nanf("");
+            if (s0 + q >= N) w = (w & ~(3u << (2 * q))) | (1u << (2 * q));
+            y[q] = (tok && s0 + q < N) ? yrow[s0 + q] : 0.0f;
         }
-        __syncthreads();
-        if (!ok) continue;
-#pragma unroll 4
-        for (int i = 0; i < kMxpChunk / 16; i++)
-        {
-            const int s = sl + 16 * i;
-            const size_t smp = c0 + s;
-            if (smp >= N) break;
-            const unsigned code = (bed[mk * clb + (smp >> 2)] >> (2 * (smp & 3))) & 3u;
-            const float valid = (code != 1u) ? 1.0f : 0.0f;
-            const float g = (code == 0u) ? 2.0f : ((code == 2u) ? 1.0f : 0.0f);
-            const float vg = valid * g;
+    };
+    auto fetch_fast = [&](size_t g, unsigned &w, float (&y)[16]) {
+        w = reinterpret_cast<const unsigned *>(rowp)[g];
+        const float4 *y4 = reinterpret_cast<const float4 *>(yrow) + g * 4;
 #pragma unroll
-            for (int k = 0; k < kMaxPhenRegs; k++)
+        for (int q = 0; q < 4; q++)
+        {
+            const float4 v = y4[q];
+            y[4 * q] = v.x;
+            y[4 * q + 1] = v.y;
+            y[4 * q + 2] = v.z;
+            y[4 * q + 3] = v.w;
+        }
+    };
+    // 8 MFMA steps of one group; lane (row r32, half kh) supplies individual 2 st + kh in step st
+    auto multiply = [&](unsigned w, const float (&y)[16]) {
+        const unsigned wk = (mok ? w : 0x55555555u) >> (2 * kh);
+        bool has_nan = false;
+#pragma unroll
+        for (int q = 0; q < 16; q++) has_nan = has_nan || (y[q] != y[q]);
+        const bool any_nan = __ballot(has_nan && tok) != 0ull;
+#pragma unroll
+        for (int st = 0; st < 8; st++)
+        {
+            const unsigned code = (wk >> (4 * st)) & 3u;           // 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0
+            const float av = (float)((0xdu >> code) & 1u);         // non-missing flag
+            const float ag = (float)((0x12u >> (2 * code)) & 3u);  // dosage, 0 when missing
+            const float yq = kh ? y[2 * st + 1] : y[2 * st];
+            const float by = (yq != yq) ? 0.0f : yq;
+            sv += av;
+            acc_gy = __builtin_amdgcn_mfma_f32_32x32x2f32(ag, by, acc_gy, 0, 0, 0);
+            acc_vy = __builtin_amdgcn_mfma_f32_32x32x2f32(av, by, acc_vy, 0, 0, 0);
+        }
+        // the NaN count product only for groups that contain a NaN, in its own loop: a branch around the
+        // products above would make the compiler copy the 32 accumulator registers at every join
+        if (any_nan)
+        {
+#pragma unroll
+            for (int st = 0; st < 8; st++)
             {
-                if (k < pcount)
-                {
-                    const float y = sy[k][s];
-                    if (!(y != y))
-                    {
-                        sgy[k] += vg * y;
-                        syv[k] += valid * y;
-                        sn[k] += valid;
-                    }
-                }
+                const unsigned code = (wk >> (4 * st)) & 3u;
+                const float av = (float)((0xdu >> code) & 1u);
+                const float yq = kh ? y[2 * st + 1] : y[2 * st];
+                acc_vn = __builtin_amdgcn_mfma_f32_32x32x2f32(av, (yq != yq) ? 1.0f : 0.0f, acc_vn, 0, 0, 0);
+            }
+        }
+    };
+
+    // the wave's range of 16-individual groups
+    const size_t groups = (N + 15) / 16;
+    const size_t gper = (groups + kMxpWaves - 1) / kMxpWaves;
+    const size_t g_begin = min(groups, (size_t)wave * gper), g_end = min(groups, g_begin + gper);
+    size_t g_fast_end = g_begin;
+    if constexpr (FAST)
+    {
+        g_fast_end = max(g_begin, min(g_end, N / 16));  // full groups of this wave
+        if (g_begin < g_fast_end)
+        {
+            unsigned w0, w1;
+            float y0[16], y1[16];
+            fetch_fast(g_begin, w0, y0);
+            for (size_t g = g_begin; g < g_fast_end; g += 2)
+            {
+                // unconditional request of the following group (clamped), then the products of the older set
+                fetch_fast(min(g + 1, g_fast_end - 1), w1, y1);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(w0, y0);
+                if (g + 1 >= g_fast_end) break;
+                fetch_fast(min(g + 2, g_fast_end - 1), w0, y0);
+                __builtin_amdgcn_sched_barrier(0);
+                multiply(w1, y1);
             }
         }
     }
-#pragma unroll
-    for (int k = 0; k < kMaxPhenRegs; k++)
+    for (size_t g = g_fast_end; g < g_end; g++)
     {
-        if (k < pcount)
+        unsigned w;
+        float y[16];
+        fetch_checked(g, w, y);
+        multiply(w, y);
+    }
+    // ---- split-K reduction in a fixed order: waves 4..7 -> 0..3, then 2,3 -> 0,1, then 1 -> 0 ----
+    s_sv[wave][lane] = sv;
+    for (int half = kMxpWaves / 2; half >= 1; half >>= 1)
+    {
+        __syncthreads();
+        if (wave >= half && wave < 2 * half)
         {
-            float a = sgy[k], b = syv[k], c = sn[k];
-            for (int o = 8; o > 0; o >>= 1)
+#pragma unroll
+            for (int r = 0; r < 16; r++)
             {
-                a += __shfl_xor(a, o);
-                b += __shfl_xor(b, o);
-                c += __shfl_xor(c, o);
+                s_part[wave - half][0][r][lane] = acc_gy[r];
+                s_part[wave - half][1][r][lane] = acc_vy[r];
+                s_part[wave - half][2][r][lane] = acc_vn[r];
             }
-            if (sl == 0 && ok)
+        }
+        __syncthreads();
+        if (wave < half)
+        {
+#pragma unroll
+            for (int r = 0; r < 16; r++)
             {
-                const float r = (a - mean[mk] * b) / (c * sd[mk]);
-                const size_t t = p0 + k;
-                if (C)
-                {
-                    C[mk * n + m + t] = r;
-                    C[(m + t) * n + mk] = r;
-                }
-                if (mxp) mxp[mk * p + t] = r;
+                acc_gy[r] += s_part[wave][0][r][lane];
+                acc_vy[r] += s_part[wave][1][r][lane];
+                acc_vn[r] += s_part[wave][2][r][lane];
             }
+        }
+    }
+    if (wave != 0) return;
+    // non-missing count per marker: both k halves of all waves, fixed order
+    float svm = 0.0f;
+#pragma unroll
+    for (int wv = 0; wv < kMxpWaves; wv++) svm += s_sv[wv][r32] + s_sv[wv][r32 + 32];
+    // C/D layout: col (trait) = lane & 31, row (marker) = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    s_sv[0][lane] = svm;  // lanes i and i+32 hold the same value for marker i
+    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_wave_barrier();
+    const size_t t = p0 + r32;
+#pragma unroll
+    for (int r = 0; r < 16; r++)
+    {
+        const int il = (r & 3) + 8 * (r >> 2) + 4 * kh;
+        const size_t mi = (size_t)blockIdx.x * 32 + il;
+        if (mi < m && tok)
+        {
+            const float cnt = s_sv[0][il] - acc_vn[r];
+            const float rr = (acc_gy[r] - mean[mi] * acc_vy[r]) / (cnt * sd[mi]);
+            if (C)
+            {
+                C[mi * n + m + t] = rr;
+                C[(m + t) * n + mi] = rr;
+            }
+            if (mxp) mxp[mi * p + t] = rr;
         }
     }
 }
@@ -607,9 +722,18 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
                                e->phen_dev.as<float>(), e->mean_dev.as<float>(), e->std_dev.as<float>(), C_dev, mxp_d, m, N,
                                p, clb, n, p0, pc);
         else
-            hipLaunchKernelGGL(mxp_tile_kernel, dim3((unsigned)((m + 15) / 16)), dim3(256), 0, s,
-                               e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
-                               e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+        {
+            const bool fast = (clb % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 3u) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(e->phen_dev.p) & 15u) == 0);
+            if (fast)
+                hipLaunchKernelGGL(mxp_mfma_kernel<true>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
+                                   e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
+                                   e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+            else
+                hipLaunchKernelGGL(mxp_mfma_kernel<false>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
+                                   e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
+                                   e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+        }
     }
     if (C_dev && p > 1)
         hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, e->phen_dev.as<float>(), C_dev, m,

@@ -75,7 +75,7 @@ struct cusk_engine
     cusk::DevBuf items[2][cusk::kNumClasses];
     cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
     long long rec_cap = 0;  // records allocated (= directed edges after level 0); rec_s is member-major with this stride
-    cusk::DevBuf rv, rpos, sel;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
+    cusk::DevBuf rv, rpos, sel, wpre;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors
     cusk::LevelCounters *hcnt = nullptr;   // kLevels entries

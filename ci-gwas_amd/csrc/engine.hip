@@ -165,7 +165,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
-                                           e->rpos.p, e->sel.as<unsigned>(), s));
+                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), s));
             return CUSK_OK;
         }
         int nonempty = 0;
@@ -292,6 +292,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             pl.pair_lds = (size_t)maxdeg_bound * 20 + 16;
             pl.use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
             pl.use_rows = (l == 1) && !het && symmetric && (e->opt_pair != 0) && (e->opt_rows != 0);
+            if (pl.use_rows) CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
             pl.use_fast = (e->opt_fast != 0) && (l >= 2);
             if (rebuilt)  // item_scan accumulates the class totals with atomics: start from zero again
                 CUSK_HIP(e, hipMemsetAsync(&dcnt[l].class_items[0], 0, sizeof(long long) * kNumClasses, s));
@@ -299,7 +300,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                                         (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
                                         a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,
                                         e->binom.as<unsigned long long>(), chunk, staged_classes, pl.use_pair ? 1 : 0,
-                                        e->rowinfo[cs].as<RowInfo>(), dcnt + l, s));
+                                        e->rowinfo[cs].as<RowInfo>(), dcnt + l, pl.use_rows ? e->wpre.as<int>() : nullptr, s));
             CUSK_HIP(e, launch_item_scan(e->rowinfo[cs].as<RowInfo>(), n, dcnt + l, s));
             int rc = sync_counters();  // the level's one host synchronisation
             if (rc != CUSK_OK) return rc;
@@ -521,7 +522,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
-                      &e->rv, &e->rpos, &e->sel, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+                      &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)

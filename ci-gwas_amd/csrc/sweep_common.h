@@ -160,7 +160,7 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
 hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
                            int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
-                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, hipStream_t st);
+                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre, hipStream_t st);
 hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
@@ -168,7 +168,7 @@ hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long r
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, hipStream_t st);
+                              unsigned *sel, const int *wpre, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

@@ -150,44 +150,87 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
     return hipGetLastError();
 }
 
-// single workgroup: off[0..n] = exclusive scan of deg, total and max degree to the level's counters
+// Exclusive scan of n ints by ONE workgroup of 1024 threads without serial dependent loads: the array is cut
+// into tiles of 1024 consecutive elements, thread t owns element t of every tile (coalesced), all tiles are
+// requested at once (one memory round trip), scanned across the wave by shuffles, and one barrier exchanges the
+// wave totals of all tiles.  kScanTiles tiles (64k elements) per round, rounds chained through a carry.
+constexpr int kScanTiles = 16;
+
+template <typename Emit>
+__device__ __forceinline__ void block_scan_1024(const int *__restrict__ in, int n, long long *s_tot, int *total_max,
+                                                long long *total_sum, Emit emit)
+{
+    // s_tot: [kScanTiles][16] wave totals
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    long long carry = 0;
+    int mx = 0;
+    for (int r0 = 0; r0 < n; r0 += kScanTiles * 1024)
+    {
+        int v[kScanTiles], incl[kScanTiles];
+#pragma unroll
+        for (int t = 0; t < kScanTiles; t++)
+        {
+            const int i = r0 + t * 1024 + tid;
+            v[t] = (i < n) ? in[i] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < kScanTiles; t++)
+        {
+            mx = max(mx, v[t]);
+            int x = v[t];
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const int y = __shfl_up(x, o);
+                if (lane >= o) x += y;
+            }
+            incl[t] = x;
+            if (lane == 63) s_tot[t * 16 + wave] = x;
+        }
+        __syncthreads();
+        long long run = carry;
+#pragma unroll
+        for (int t = 0; t < kScanTiles; t++)
+        {
+            long long before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < 16; w++)
+            {
+                const long long c = s_tot[t * 16 + w];
+                if (w < wave) before += c;
+                all += c;
+            }
+            const int i = r0 + t * 1024 + tid;
+            if (i < n) emit(i, run + before + incl[t] - v[t]);
+            run += all;
+        }
+        carry = run;
+        __syncthreads();
+    }
+    // maximum over the block
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
+    if (lane == 0) s_tot[wave] = mx;
+    __syncthreads();
+    if (tid == 0)
+    {
+        int m2 = 0;
+        for (int w = 0; w < 16; w++) m2 = max(m2, (int)s_tot[w]);
+        *total_max = m2;
+        *total_sum = carry;
+    }
+}
+
+// single workgroup: off = exclusive scan of the degrees; total edges and maximum degree of the level
 __global__ void __launch_bounds__(1024) scan_degrees_kernel(const int *deg, int *off, int n, LevelCounters *cnt)
 {
-    __shared__ long long s_part[1024];
-    __shared__ int s_max[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
-    long long s = 0;
-    int mx = 0;
-    for (int i = lo; i < hi; i++)
+    __shared__ long long s_tot[kScanTiles * 16];
+    __shared__ int s_max;
+    __shared__ long long s_sum;
+    block_scan_1024(deg, n, s_tot, &s_max, &s_sum, [&](int i, long long e) { off[i] = (int)e; });
+    if (threadIdx.x == 0)
     {
-        const int d = deg[i];
-        s += d;
-        mx = max(mx, d);
-    }
-    s_part[threadIdx.x] = s;
-    s_max[threadIdx.x] = mx;
-    __syncthreads();
-    for (int step = 1; step < 1024; step <<= 1)
-    {
-        const long long v = (threadIdx.x >= step) ? s_part[threadIdx.x - step] : 0;
-        const int m2 = (threadIdx.x >= step) ? s_max[threadIdx.x - step] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        s_max[threadIdx.x] = max(s_max[threadIdx.x], m2);
-        __syncthreads();
-    }
-    long long run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
-    for (int i = lo; i < hi; i++)
-    {
-        off[i] = (int)run;
-        run += deg[i];
-    }
-    if (threadIdx.x == 1023)
-    {
-        off[n] = (int)s_part[1023];
-        cnt->total_edges = s_part[1023];
-        cnt->maxdeg = s_max[1023];
+        off[n] = (int)s_sum;
+        cnt->total_edges = s_sum;
+        cnt->maxdeg = s_max;
     }
 }
 
@@ -201,7 +244,7 @@ hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *c
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
                                 unsigned long long *best, int *rowfound, int n, int words, int L,
                                 const unsigned long long *__restrict__ binom, unsigned long long chunk,
-                                int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt)
+                                int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -220,6 +263,9 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
             if (lane >= o) incl += v;
         }
         int pos = o0 + run + incl - c;
+        // list position of the word's first neighbour: lets anyone turn (row, column) into a list position with
+        // one more popcount (level1_prep_kernel)
+        if (wpre && w < words) wpre[(size_t)row * words + w] = run + incl - c;
         while (bits)
         {
             const int b = __ffsll((long long)bits) - 1;
@@ -260,10 +306,10 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
 
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
                            int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
-                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, hipStream_t st)
+                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre, hipStream_t st)
 {
     hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, L, binom,
-                       chunk, staged_classes, pair_mode, rowinfo, cnt);
+                       chunk, staged_classes, pair_mode, rowinfo, cnt, wpre);
     return hipGetLastError();
 }
 
@@ -348,30 +394,14 @@ hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, 
 __global__ void __launch_bounds__(1024) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
                                                          long long *rec_base, int level)
 {
-    __shared__ int s_part[1024];
-    const int per = (n + 1023) / 1024;
-    const int lo = threadIdx.x * per, hi = min(n, lo + per);
-    int s = 0;
-    for (int i = lo; i < hi; i++) s += rowfound[i];
-    s_part[threadIdx.x] = s;
-    __syncthreads();
-    for (int step = 1; step < 1024; step <<= 1)
+    __shared__ long long s_tot[kScanTiles * 16];
+    __shared__ int s_max;
+    __shared__ long long s_sum;
+    block_scan_1024(rowfound, n, s_tot, &s_max, &s_sum, [&](int i, long long e) { recoff[i] = (int)e; });
+    if (threadIdx.x == 0)
     {
-        const int v = (threadIdx.x >= step) ? s_part[threadIdx.x - step] : 0;
-        __syncthreads();
-        s_part[threadIdx.x] += v;
-        __syncthreads();
-    }
-    int run = (threadIdx.x == 0) ? 0 : s_part[threadIdx.x - 1];
-    for (int i = lo; i < hi; i++)
-    {
-        recoff[i] = run;
-        run += rowfound[i];
-    }
-    if (threadIdx.x == 1023)
-    {
-        cnt->rec_total = (unsigned long long)s_part[1023];
-        rec_base[level + 1] = rec_base[level] + s_part[1023];
+        cnt->rec_total = (unsigned long long)s_sum;
+        rec_base[level + 1] = rec_base[level] + s_sum;
     }
 }
 
@@ -555,29 +585,24 @@ hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t 
 constexpr unsigned kNone32 = 0xffffffffu;
 
 __global__ void level1_prep_kernel(const float *__restrict__ C, const int *__restrict__ off, const int *__restrict__ nbr,
+                                   const unsigned long long *__restrict__ adj, const int *__restrict__ wpre, int words,
                                    float *rv, int4 *meta, unsigned *sel, int n)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
     const int o0 = off[row], d = off[row + 1] - o0;
+    const int rw = row >> 6;
+    const unsigned long long below = (1ull << (row & 63)) - 1ull;
     for (int k = lane; k < d; k += 64)
     {
         const int y = nbr[o0 + k];
         rv[o0 + k] = C[(size_t)row * n + y];
         sel[o0 + k] = kNone32;
-        const int oy = off[y];
-        const int dy = off[y + 1] - oy;
-        int lo = 0, hi = dy;
-        while (lo < hi)
-        {
-            const int mid = (lo + hi) >> 1;
-            if (nbr[oy + mid] < row)
-                lo = mid + 1;
-            else
-                hi = mid;
-        }
-        meta[o0 + k] = make_int4(y, lo, oy, dy);
+        // position of `row` in y's ascending list = neighbours of y below `row`: the word prefix written by
+        // fill_nbr plus one popcount -- two independent loads instead of a binary search
+        const int pos = wpre[(size_t)y * words + rw] + __popcll(adj[(size_t)y * words + rw] & below);
+        meta[o0 + k] = make_int4(y, pos, off[y], off[y + 1] - off[y]);
     }
 }
 
@@ -911,10 +936,10 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
 }
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, hipStream_t st)
+                              unsigned *sel, const int *wpre, hipStream_t st)
 {
     const int n = p.n;
-    hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, rv,
+    hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
                        static_cast<int4 *>(meta), sel, n);
     RowsParams rp;
     rp.rv = rv;
