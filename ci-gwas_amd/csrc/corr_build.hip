@@ -343,6 +343,189 @@ __global__ void __launch_bounds__(256, 2) mxm_mfma_kernel(const unsigned char *_
     }
 }
 
+// ---------------------------------------------------------------------------
+// The same nine contingency GEMMs on the FP4 matrix pipe (v_mfma_scale_f32_32x32x64_f8f6f4, twice the int8
+// rate).  The operands are 0/1 indicators, so e2m1 holds them exactly and the f32 accumulation is exact (counts
+// <= 2^24).  Two observations make the decode almost free:
+//   * a dot product over individuals does not care about their ORDER, as long as both operands use the same
+//     one.  A plane word has its 16 indicator bits at the even bit positions; (x & 0x11111111) is already a
+//     valid word of eight 4-bit elements (individuals 0,2,4,...) and ((x >> 2) & 0x11111111) the other eight:
+//     two ANDs and a shift instead of a bit-spreading multiply per four individuals;
+//   * the element those masks produce is 0b0001 = 0.5 in e2m1, so every product is 0.25 and the accumulator
+//     holds count/4, exactly; the epilogue multiplies by 4.
+// Workgroup = 4 waves (2x2), tile 64 x 64 marker pairs, K block = 256 individuals = four MFMA steps of 64; each
+// thread decodes 128 individuals of one tile marker per block (32 bytes of .bed) into 3 planes x 4 fragments of
+// 16 bytes, stored in fragment order ([plane][k-step][lane half][row]), 48 KB for both operands.
+// ---------------------------------------------------------------------------
+typedef int v8i __attribute__((ext_vector_type(8)));
+typedef float v16f __attribute__((ext_vector_type(16)));
+constexpr int kKB4 = 256;        // individuals per K block
+constexpr int kKS4 = kKB4 / 64;  // MFMA steps per K block
+
+__global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__restrict__ bed, float *C, size_t m, size_t N,
+                                                          size_t clb, size_t n, int tiles)
+{
+    __shared__ v4i sA[3][kKS4][2][kMT];
+    __shared__ v4i sB[3][kKS4][2][kMT];
+    int t = blockIdx.x, bi = 0;
+    {
+        int rem = t, len = tiles;
+        while (rem >= len)
+        {
+            rem -= len;
+            len--;
+            bi++;
+        }
+        t = bi + rem;
+    }
+    const int bj = t;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    // decode role: tile-local marker (0..63 rows of A, 64..127 rows of B) and 128-individual half of the K block
+    const int row_l = tid >> 1, q = tid & 1;
+    const size_t mk = (row_l < kMT) ? (size_t)bi * kMT + row_l : (size_t)bj * kMT + (row_l - kMT);
+    const bool row_ok = mk < m;
+    const unsigned char *rowp = bed + (row_ok ? mk : 0) * clb;
+    v4i(*dst)[kKS4][2][kMT] = (row_l < kMT) ? sA : sB;
+    const int rr = row_l & (kMT - 1);
+
+    v16f acc[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int b = 0; b < 3; b++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[a][b][r] = 0.0f;
+
+    const size_t nkb = (N + kKB4 - 1) / kKB4;
+    // 32 bytes of the marker's row: individuals [kb*256 + q*128, +128)
+    auto load32 = [&](size_t kb, unsigned (&w)[8]) {
+        const size_t off = kb * (kKB4 / 4) + (size_t)q * 32;
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = 0u;
+        if (row_ok && off < clb)
+        {
+            const unsigned char *src = rowp + off;
+            if (off + 32 <= clb && ((reinterpret_cast<uintptr_t>(src) & 15u) == 0))
+            {
+                const uint4 lo = reinterpret_cast<const uint4 *>(src)[0], hi = reinterpret_cast<const uint4 *>(src)[1];
+                w[0] = lo.x, w[1] = lo.y, w[2] = lo.z, w[3] = lo.w;
+                w[4] = hi.x, w[5] = hi.y, w[6] = hi.z, w[7] = hi.w;
+            }
+            else
+            {
+                for (size_t b = 0; b < 32 && off + b < clb; b++) w[b >> 2] |= (unsigned)src[b] << (8 * (b & 3));
+            }
+        }
+    };
+    unsigned w[8];
+    load32(0, w);
+    const int scale1 = 0x7f7f7f7f;  // E8M0 127 = 2^0 for every block
+    for (size_t kb = 0; kb < nkb; kb++)
+    {
+        const size_t base = kb * kKB4 + (size_t)q * 128;
+#pragma unroll
+        for (int u2 = 0; u2 < 4; u2++)
+        {
+            // two code words = 32 individuals = one fragment (k-step 2q + (u2 >> 1), lane half u2 & 1) per plane
+            unsigned pe[3][2], po[3][2];
+#pragma unroll
+            for (int z = 0; z < 2; z++)
+            {
+                const int u = 2 * u2 + z;
+                // individuals at or beyond N (padding bits, or past the file) count as missing
+                const size_t s0 = base + 16 * u;
+                const unsigned nv = (!row_ok || s0 >= N) ? 0u : (unsigned)min((size_t)16, N - s0);
+                const unsigned msk = (nv >= 16u) ? 0x55555555u : (((1u << (2 * nv)) - 1u) & 0x55555555u);
+                const unsigned lo = w[u] & 0x55555555u, hi = (w[u] >> 1) & 0x55555555u;
+                const unsigned pl[3] = {hi & ~lo & msk,     // code 10 -> genotype 1
+                                        ~hi & ~lo & msk,    // code 00 -> genotype 2
+                                        (hi | ~lo) & msk};  // anything but 01 (missing)
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                {
+                    pe[k][z] = pl[k] & 0x11111111u;
+                    po[k][z] = (pl[k] >> 2) & 0x11111111u;
+                }
+            }
+            const int ks = 2 * q + (u2 >> 1), h = u2 & 1;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+            {
+                v4i f;
+                f.x = (int)pe[k][0];
+                f.y = (int)po[k][0];
+                f.z = (int)pe[k][1];
+                f.w = (int)po[k][1];
+                dst[k][ks][h][rr] = f;
+            }
+        }
+        if (kb + 1 < nkb) load32(kb + 1, w);  // in flight while the MFMAs run
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < kKS4; ks++)
+        {
+            v8i a[3], b[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; pl++)
+            {
+                const v4i fa = sA[pl][ks][lane >> 5][wr * 32 + (lane & 31)];
+                const v4i fb = sB[pl][ks][lane >> 5][wc * 32 + (lane & 31)];
+                a[pl] = v8i{fa.x, fa.y, fa.z, fa.w, 0, 0, 0, 0};
+                b[pl] = v8i{fb.x, fb.y, fb.z, fb.w, 0, 0, 0, 0};
+            }
+#pragma unroll
+            for (int pa = 0; pa < 3; pa++)
+#pragma unroll
+                for (int pb = 0; pb < 3; pb++)
+                    acc[pa][pb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[pa], b[pb], acc[pa][pb], 4, 4, 0, scale1, 0,
+                                                                                  scale1);
+        }
+        __syncthreads();
+    }
+
+    // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+    float *scratch = reinterpret_cast<float *>(&sA[0][0][0][0]) + wave * (32 * 33);
+    const size_t i0 = (size_t)bi * kMT + wr * 32, j0 = (size_t)bj * kMT + wc * 32;
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int rl = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5), cl = lane & 31;
+        const size_t i = i0 + rl, j = j0 + cl;
+        float r = 0.0f;
+        if (i < m && j < m && i < j)
+        {
+            // every product was 0.5 * 0.5: the accumulators hold count / 4 exactly
+            const unsigned n11 = (unsigned)(acc[0][0][e] * 4.0f), n12 = (unsigned)(acc[0][1][e] * 4.0f),
+                           n21 = (unsigned)(acc[1][0][e] * 4.0f), n22 = (unsigned)(acc[1][1][e] * 4.0f),
+                           n1v = (unsigned)(acc[0][2][e] * 4.0f), n2v = (unsigned)(acc[1][2][e] * 4.0f),
+                           nv1 = (unsigned)(acc[2][0][e] * 4.0f), nv2 = (unsigned)(acc[2][1][e] * 4.0f),
+                           nvv = (unsigned)(acc[2][2][e] * 4.0f);
+            float s[9];
+            s[4] = (float)n11;
+            s[5] = (float)n12;
+            s[7] = (float)n21;
+            s[8] = (float)n22;
+            s[3] = (float)(n1v - n11 - n12);
+            s[6] = (float)(n2v - n21 - n22);
+            s[1] = (float)(nv1 - n11 - n21);
+            s[2] = (float)(nv2 - n12 - n22);
+            s[0] = (float)(nvv - n1v - n2v - (nv1 - n11 - n21) - (nv2 - n12 - n22));
+            r = npn_from_counts(s);
+            C[i * n + j] = r;
+        }
+        scratch[cl * 33 + rl] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 16; e++)
+    {
+        const int jl = 2 * e + (lane >> 5), il = lane & 31;
+        const size_t i = i0 + il, j = j0 + jl;
+        if (i < m && j < m && i < j) C[j * n + i] = scratch[jl * 33 + il];
+    }
+}
+
 // one wave per marker, all traits: Pearson of corr_kernels.cu:157-238
 constexpr int kMaxPhenRegs = 32;
 __global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restrict__ bed, const float *__restrict__ phen,
@@ -424,7 +607,6 @@ __global__ void __launch_bounds__(256) mxp_kernel(const unsigned char *__restric
 // each: lane (i, k) walks marker i and takes individuals 2q+k of each byte (two MFMA steps per .bed byte), lane
 // (j, k) walks trait row j with float4 loads.  The NaN product is only issued for 16-individual groups that
 // contain a NaN.
-typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kMxpWaves = 8;
 
 // FAST: every marker row of the .bed block is dword-aligned and every trait row 16-byte aligned (N % 4 == 0 and
@@ -705,8 +887,12 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kMT - 1) / kMT);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
-        hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m, N,
-                           clb, n, tiles);
+        if (e->opt_corr_fp4)
+            hipLaunchKernelGGL(mxm_fp4_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m, N,
+                               clb, n, tiles);
+        else
+            hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m,
+                               N, clb, n, tiles);
         hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C_dev, n);
     }
     else

@@ -90,6 +90,7 @@ struct cusk_engine
     // options (cusk_engine_set_option)
     int opt_fast = 1;
     int opt_validate = 0;
+    int opt_corr_fp4 = 1;
     int opt_pair = 1;
     int opt_rows = 1;
     int opt_vec = 1;

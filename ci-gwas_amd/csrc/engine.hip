@@ -555,6 +555,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_fast = (int)value;
     else if (k == "validate")
         e->opt_validate = (int)value;
+    else if (k == "corr_fp4")
+        e->opt_corr_fp4 = (int)value;
     else if (k == "pair")
         e->opt_pair = (int)value;
     else if (k == "rows")

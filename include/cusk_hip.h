@@ -115,8 +115,9 @@ const char *cusk_last_error(const cusk_engine *e);
  * symmetric matrix; 0: generic staged kernel), "rows" (default 1: the row-streaming level-1 kernel that reads C
  * exactly once; 0: the pair-gather kernel), "vec" (default 1: vectorised
  * four-tests-per-ds_read_b128 sweep kernel; 0: scalar fast kernel), "overlap" (default 1: independent degree
- * classes and the winners' exact z run on an auxiliary stream), "corr_popcount" (default 0: int8 MFMA contingency GEMM in
- * cusk_corr_build; 1: bit-plane AND/popcount cross-check kernel), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
+ * classes and the winners' exact z run on an auxiliary stream), "corr_fp4" (default 1: the SNP x SNP contingency GEMMs of
+ * cusk_corr_build on the FP4 matrix pipe; 0: the int8 MFMA form), "corr_popcount" (default 0; 1: bit-plane AND/popcount
+ * cross-check kernels instead of the matrix cores), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
  * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);

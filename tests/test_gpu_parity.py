@@ -291,22 +291,27 @@ def test_corr_build_vs_oracle(cg, eng, oracle, synth, m, N, p):
     Cd.free()
 
 
-def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth):
-    """the int8 MFMA contingency GEMM and the bit-plane popcount kernel give identical matrices"""
-    m, N, p = 200, 1500, 3
+@pytest.mark.parametrize("m,N", [(200, 1500), (130, 4096), (70, 777)])
+def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth, m, N):
+    """the FP4 MFMA contingency GEMM (default), the int8 MFMA one and the bit-plane popcount kernel give identical
+    SNP x SNP matrices, equal to the oracle's (N with and without a partial last K block / byte)"""
+    p = 3
     bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=4, miss=0.02)
     n = m + p
     outs = []
-    for popc in (0, 1):
+    for opts in ({"corr_fp4": 1}, {"corr_fp4": 0}, {"corr_popcount": 1}):
         e = cg.Engine(0)
-        e.set_option("corr_popcount", popc)
+        for k, v in opts.items():
+            e.set_option(k, v)
         Cd = cg.DeviceArray(nbytes=4 * n * n)
         e.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr)
         outs.append(Cd.download(np.float32, (n, n)))
         Cd.free()
         e.close()
     assert np.array_equal(outs[0][:m, :m], outs[1][:m, :m], equal_nan=True)
-    assert np.allclose(outs[0], outs[1], atol=1e-6, rtol=0, equal_nan=True)  # SNP x trait: different summation orders
+    assert np.array_equal(outs[0][:m, :m], outs[2][:m, :m], equal_nan=True)
+    assert np.array_equal(outs[0], outs[1], equal_nan=True)
+    assert np.allclose(outs[0], outs[2], atol=1e-6, rtol=0, equal_nan=True)  # SNP x trait: different summation orders
     o_mxm, _, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
     iu = np.triu_indices(m, 1)
     assert np.array_equal(outs[0][:m, :m][iu], o_mxm, equal_nan=True)
