@@ -13,6 +13,7 @@
 // sweep can start without a host round trip.
 //
 // .bed 2-bit codes, low bits first: 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0.
+#include <type_traits>
 #include <cmath>
 #include <vector>
 
@@ -358,10 +359,17 @@ __global__ void __launch_bounds__(256, 2) mxm_mfma_kernel(const unsigned char *_
 // 16 bytes, stored in fragment order ([plane][k-step][lane half][row]), 48 KB for both operands.
 // ---------------------------------------------------------------------------
 typedef int v8i __attribute__((ext_vector_type(8)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+// Workgroup barrier that only drains the LDS queue.  __syncthreads() also waits for every outstanding global
+// load (vmcnt(0)), which would cancel the two-blocks-ahead .bed requests of the K loop below.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kKB4 = 256;        // individuals per K block
 constexpr int kKS4 = kKB4 / 64;  // MFMA steps per K block
 
+template <bool FAST>
 __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__restrict__ bed, float *C, size_t m, size_t N,
                                                           size_t clb, size_t n, int tiles)
 {
@@ -418,11 +426,10 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
             }
         }
     };
-    unsigned w[8];
-    load32(0, w);
     const int scale1 = 0x7f7f7f7f;  // E8M0 127 = 2^0 for every block
-    for (size_t kb = 0; kb < nkb; kb++)
-    {
+    // one K block: decode 128 individuals of this thread's marker into LDS fragments ...
+    auto decode = [&](size_t kb, const unsigned (&w)[8], auto full_tag) {
+        constexpr bool FULL = decltype(full_tag)::value;  // every individual of the block exists (kb < N / 256)
         const size_t base = kb * kKB4 + (size_t)q * 128;
 #pragma unroll
         for (int u2 = 0; u2 < 4; u2++)
@@ -434,9 +441,15 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
             {
                 const int u = 2 * u2 + z;
                 // individuals at or beyond N (padding bits, or past the file) count as missing
-                const size_t s0 = base + 16 * u;
-                const unsigned nv = (!row_ok || s0 >= N) ? 0u : (unsigned)min((size_t)16, N - s0);
-                const unsigned msk = (nv >= 16u) ? 0x55555555u : (((1u << (2 * nv)) - 1u) & 0x55555555u);
+                unsigned msk;
+                if constexpr (FULL)
+                    msk = row_ok ? 0x55555555u : 0u;
+                else
+                {
+                    const size_t s0 = base + 16 * u;
+                    const unsigned nv = (!row_ok || s0 >= N) ? 0u : (unsigned)min((size_t)16, N - s0);
+                    msk = (nv >= 16u) ? 0x55555555u : (((1u << (2 * nv)) - 1u) & 0x55555555u);
+                }
                 const unsigned lo = w[u] & 0x55555555u, hi = (w[u] >> 1) & 0x55555555u;
                 const unsigned pl[3] = {hi & ~lo & msk,     // code 10 -> genotype 1
                                         ~hi & ~lo & msk,    // code 00 -> genotype 2
@@ -460,8 +473,9 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
                 dst[k][ks][h][rr] = f;
             }
         }
-        if (kb + 1 < nkb) load32(kb + 1, w);  // in flight while the MFMAs run
-        __syncthreads();
+    };
+    // ... and the 4 x 9 products of this wave's 32 x 32 sub-tile
+    auto products = [&]() {
 #pragma unroll
         for (int ks = 0; ks < kKS4; ks++)
         {
@@ -481,6 +495,67 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
                     acc[pa][pb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a[pa], b[pb], acc[pa][pb], 4, 4, 0, scale1, 0,
                                                                                   scale1);
         }
+    };
+    // Full K blocks of 16-byte aligned rows (FAST, checked by the launcher) are requested two blocks ahead with
+    // unconditional loads into two alternating register sets: .bed comes from L2/HBM with a latency of several
+    // K blocks' worth of MFMAs.  Rows without a marker read row 0 and are masked in the decode.
+    size_t kb0 = 0;
+    if constexpr (FAST)
+    {
+        const size_t nfull = N / kKB4;
+        const uint4 *row4 = reinterpret_cast<const uint4 *>(rowp) + 2 * q;
+        // The requests are issued as inline assembly so that NO compiler-generated s_waitcnt covers them: hipcc
+        // drains the whole load queue (vmcnt(0)) at the first use inside a loop, which would serialise request and
+        // use again.  Each register set is waited for explicitly, with exactly the other set's two loads allowed
+        // to stay in flight, and everything is drained before the registers can be reused after the loop.
+#define CUSK_BED_REQUEST(kb_, lo_, hi_)                                                                          \
+    {                                                                                                          \
+        const uint4 *src_ = row4 + (kb_) * (kKB4 / 64);                                                        \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16"            \
+                     : "=&v"(lo_), "=&v"(hi_)                                                                  \
+                     : "v"(src_)                                                                               \
+                     : "memory");                                                                              \
+    }
+#define CUSK_BED_WAIT_OLDER(lo_, hi_) asm volatile("s_waitcnt vmcnt(2)" : "+v"(lo_), "+v"(hi_)::"memory")
+        if (nfull > 0)
+        {
+            v4u alo, ahi, blo, bhi;  // native vectors: register operands of the assembly
+            unsigned w[8];
+            CUSK_BED_REQUEST(0, alo, ahi);
+            CUSK_BED_REQUEST(min((size_t)1, nfull - 1), blo, bhi);
+            for (size_t kb = 0; kb < nfull; kb += 2)
+            {
+                CUSK_BED_WAIT_OLDER(alo, ahi);
+                w[0] = alo.x, w[1] = alo.y, w[2] = alo.z, w[3] = alo.w;
+                w[4] = ahi.x, w[5] = ahi.y, w[6] = ahi.z, w[7] = ahi.w;
+                decode(kb, w, std::true_type{});
+                CUSK_BED_REQUEST(min(kb + 2, nfull - 1), alo, ahi);
+                lds_barrier();
+                products();
+                lds_barrier();
+                if (kb + 1 >= nfull) break;
+                CUSK_BED_WAIT_OLDER(blo, bhi);
+                w[0] = blo.x, w[1] = blo.y, w[2] = blo.z, w[3] = blo.w;
+                w[4] = bhi.x, w[5] = bhi.y, w[6] = bhi.z, w[7] = bhi.w;
+                decode(kb + 1, w, std::true_type{});
+                CUSK_BED_REQUEST(min(kb + 3, nfull - 1), blo, bhi);
+                lds_barrier();
+                products();
+                lds_barrier();
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(alo), "+v"(ahi), "+v"(blo), "+v"(bhi)::"memory");
+#undef CUSK_BED_REQUEST
+#undef CUSK_BED_WAIT_OLDER
+            kb0 = nfull;
+        }
+    }
+    for (size_t kb = kb0; kb < nkb; kb++)
+    {
+        unsigned w[8];
+        load32(kb, w);
+        decode(kb, w, std::false_type{});
+        __syncthreads();
+        products();
         __syncthreads();
     }
 
@@ -887,9 +962,13 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kMT - 1) / kMT);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
-        if (e->opt_corr_fp4)
-            hipLaunchKernelGGL(mxm_fp4_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m, N,
-                               clb, n, tiles);
+        const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 15u) == 0);
+        if (e->opt_corr_fp4 && rows16)
+            hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
+                               m, N, clb, n, tiles);
+        else if (e->opt_corr_fp4)
+            hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
+                               m, N, clb, n, tiles);
         else
             hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m,
                                N, clb, n, tiles);
