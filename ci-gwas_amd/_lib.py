@@ -25,6 +25,7 @@ class CuskStats(C.Structure):
         ("rechecks", C.c_longlong * (ML + 1)),
         ("violations", C.c_longlong),
         ("exact_fallbacks", C.c_longlong),
+        ("main_kernel_ms", C.c_float * (ML + 1)),
     ]
 
 

@@ -155,6 +155,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     long long cap_edges = 0;  // allocation bound for the CSR arrays (edges only shrink)
     int level_out = (a.maxlevel < 0) ? 0 : last_level + 1;
     int levels_swept = 0;
+    bool rows_timed = false;
 
     auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
         LevelPlan &pl = plan[l];
@@ -165,7 +166,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
-                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), s));
+                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->ev_main[0], e->ev_main[1], s));
+            rows_timed = true;
             return CUSK_OK;
         }
         int nonempty = 0;
@@ -439,6 +441,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         local.rechecks[l] = (long long)e->hcnt[l].qcount;
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_k0[l], e->ev_k1[l]));
         local.kernel_ms[l] = ms;
+        local.main_kernel_ms[l] = ms;
+        if (l == 1 && rows_timed)
+        {
+            CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_main[0], e->ev_main[1]));
+            local.main_kernel_ms[l] = ms;
+        }
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[l], e->ev_l1[l]));
         local.level_ms[l] = ms;
     }
@@ -501,6 +509,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     }
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;
     for (auto &ev : e->ev_run) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    for (auto &ev : e->ev_main) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (auto &ev : e->ev_corr) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int l = 0; l < kLevels; l++)
     {
@@ -533,6 +542,8 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     if (e->hcnt) (void)hipHostFree(e->hcnt);
     if (e->hflag) (void)hipHostFree(e->hflag);
     for (auto &ev : e->ev_run)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : e->ev_main)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : e->ev_corr)
         if (ev) (void)hipEventDestroy(ev);

@@ -168,7 +168,7 @@ hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long r
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, const int *wpre, hipStream_t st);
+                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

@@ -936,7 +936,7 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
 }
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, const int *wpre, hipStream_t st)
+                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -948,6 +948,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.use_filter = use_filter ? 1 : 0;
     const dim3 grid((unsigned)n);
     const dim3 blk(kRowsThreads);
+    if (ev_begin) (void)hipEventRecord(ev_begin, st);
     if (mode == 0 && !validate)
         hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, 0, st, p, rp);
     else if (mode == 0)
@@ -956,6 +957,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
         hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, 0, st, p, rp);
     else
         hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
+    if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode == 0)
         hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
                            p.slots);

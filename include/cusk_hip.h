@@ -102,6 +102,8 @@ typedef struct cusk_stats {
     long long rechecks[CUSK_ML + 1];  /* tests the fast filter could not certify (re-evaluated on the exact path) */
     long long violations;             /* validate mode only: certified verdicts contradicted by the exact path */
     long long exact_fallbacks;        /* levels redone entirely on the exact path (recheck queue overflow) */
+    float main_kernel_ms[CUSK_ML + 1]; /* HIP-event time of the level's dominant kernel alone (level 1: the rows
+                                         kernel without its prep / count passes; other levels = kernel_ms) */
 } cusk_stats;
 
 /* device = HIP device ordinal; stream = a hipStream_t to run on, or NULL for a

@@ -1,0 +1,41 @@
+# Profiles of the default bench for profiles/<tag>_*: run on the GPU box from the repo root:  bash tools/profile_round.sh <tag>
+# 1. plain bench line; 2. rocprofv3 --kernel-trace --stats; 3. PMC passes (separate runs): FETCH_SIZE | WRITE_SIZE | SQ set
+TAG=${1:-r01}; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
+python3 -c "import torch" > /dev/null 2>&1
+timeout -k 10 600 python3 bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1 && grep '^{' $O/bench.log > $O/${TAG}_bench.json
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/trace.log 2>&1)
+cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats.csv
+i=0
+for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $O/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc$i.log 2>&1)
+done
+python3 - "$O" "$TAG" <<'PY'
+import csv, glob, sys, collections, json
+O, TAG = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: [0.0, 0])
+for f in glob.glob(O + "/pmc*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+with open(f"{O}/{TAG}_pmc_summary.txt", "w") as out:
+    out.write("rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (MI355X, three separate passes:\n"
+              "FETCH_SIZE | WRITE_SIZE | SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)\n"
+              "per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them\n\n")
+    last = None
+    for (kn, cn), (v, c) in sorted(acc.items()):
+        if kn != last:
+            out.write(kn + "\n"); last = kn
+        out.write(f"    {cn:28s} launches {c:4d}  avg {v/c:.5g}\n")
+def per_launch(kpat):
+    f = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "FETCH_SIZE"]
+    w = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "WRITE_SIZE"]
+    return (f[0] if f else 0.0) * 1024, (w[0] if w else 0.0) * 1024
+f1, w1 = per_launch("level1_rows_kernel")
+json.dump({"level1": f1 + w1, "level1_fetch": f1, "level1_write": w1,
+           "note": "HBM-side bytes per launch of level1_rows_kernel<0,false> = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate PMC "
+                   "passes (" + TAG + "); FETCH_SIZE taken as reported: the kernel's reads are 4-byte-per-lane streams and gathers, "
+                   "not the 16-byte-per-lane streams the gfx950 2x correction applies to"},
+          open(f"{O}/pmc_traffic.json", "w"), indent=1)
+PY
+ls $O | head -30
