@@ -3,6 +3,7 @@
 // Replaces /root/reference/cusk/src/cuPC-S.cu:458-484 (cal_Indepl0), :6355-6432 (scan_compact),
 // :486-582 (cal_Indepl1) and their hetcor twins (src/hetcor-cuPC-S.cu:343-486).
 #include <algorithm>
+#include <cmath>
 #include <type_traits>
 
 #include "ci_exact.h"
@@ -42,10 +43,15 @@ __global__ void init_bits_kernel(unsigned long long *adj, const int *Ginit, int 
 // coalesced 256-byte row segments in, wavefront ballots out (one 64-bit adjacency word per
 // tile row, plus the mirrored word through LDS).  The mirrored tile is loaded as well so that
 // level 0 also answers "is C bitwise symmetric?" (level 1 then reads only the upper triangle).
+// Without per-pair sample sizes the level-0 verdict z(|c|) < th is a comparison of |c| with tanh(th): outside
+// a guard band around that value (c_lo, c_hi from the host, +-5e-4 relative, far above the fp32 error of the
+// reference's Fisher z) two compares settle the element, inside it (and for NaN or |c| > 1, where the reference's
+// formula is not monotone) the reference's arithmetic decides.  All 16 rows of a wave are requested before the
+// first is evaluated.
 template <bool ESS, bool SYMCHECK>
 __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C, const float *__restrict__ N,
-                                                      unsigned long long *adj, int n, int words, float th, int tiles,
-                                                      int *asym_flag)
+                                                      unsigned long long *adj, int n, int words, float th, float c_lo,
+                                                      float c_hi, int tiles, int *asym_flag)
 {
     __shared__ unsigned long long s_col[64];
     __shared__ float s_t[64][65];
@@ -74,8 +80,19 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
     }
     __syncthreads();
     const int j = bj * 64 + lane;
+    float cv[16];
+    [[maybe_unused]] float nv[16];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int i = bi * 64 + wave * 16 + rr;
+        const bool in = (i < n && j < n && i < j);
+        cv[rr] = in ? C[(size_t)i * n + j] : 0.0f;
+        if constexpr (ESS) nv[rr] = in ? N[(size_t)i * n + j] : 4.0f;
+    }
     unsigned long long colbits = 0ull;
     bool asym = false;
+#pragma unroll
     for (int rr = 0; rr < 16; rr++)
     {
         const int r = wave * 16 + rr;
@@ -83,15 +100,27 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
         bool rm = false;
         if (i < n && j < n && i < j)
         {
-            const float c = C[(size_t)i * n + j];
+            const float c = cv[rr];
             if constexpr (SYMCHECK)
             {
                 const float ct = s_t[lane][r];
                 asym |= (__float_as_uint(c) != __float_as_uint(ct)) && !((c != c) && (ct != ct));
             }
-            float lth = th;
-            if constexpr (ESS) lth = (float)((double)th / sqrt((double)N[(size_t)i * n + j] - 3.0));
-            rm = z_below<false>(c, lth);
+            if constexpr (ESS)
+            {
+                const float lth = (float)((double)th / sqrt((double)nv[rr] - 3.0));
+                rm = z_below<false>(c, lth);
+            }
+            else
+            {
+                const float ac = fabsf(c);
+                if (ac < c_lo)
+                    rm = true;
+                else if (ac > c_hi && ac <= 1.0f)
+                    rm = false;
+                else
+                    rm = z_below<false>(c, th);
+            }
         }
         const unsigned long long m = __ballot(rm);
         if (lane == 0 && m != 0ull) atomicAnd(&adj[(size_t)i * words + bj], ~m);
@@ -111,6 +140,100 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
     }
 }
 
+// Wide-tile form for the common case (one threshold, symmetry not checked): 64 rows x 256 columns per workgroup,
+// so every row contributes a contiguous 1 KB to the stream instead of 256 B (DRAM pages are opened for a useful
+// amount of data).  Lane l of a wave takes columns l, l+64, l+128, l+192 of its 16 rows: four coalesced 256-byte
+// loads per row whose ballots are directly the four bitmap words; the mirrored words go through LDS.
+constexpr int kL0Cols = 256;
+__global__ void __launch_bounds__(256) level0_wide_kernel(const float *__restrict__ C, unsigned long long *adj, int n, int words,
+                                                           float th, float c_lo, float c_hi, int col_tiles, int complete_graph)
+{
+    __shared__ unsigned long long s_col[kL0Cols];
+    // tile (bi, bj): rows [64 bi, +64), columns [256 bj, +256); only tiles that reach right of the diagonal
+    int bi = 0, t = blockIdx.x;
+    {
+        // row block bi has col_tiles - (bi / 4) column tiles (its first one contains the diagonal)
+        for (;;)
+        {
+            const int len = col_tiles - (bi >> 2);
+            if (t < len) break;
+            t -= len;
+            bi++;
+        }
+    }
+    const int bj = (bi >> 2) + t;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    s_col[threadIdx.x] = 0ull;
+    __syncthreads();
+    float cv[16][4];
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int i = bi * 64 + wave * 16 + rr;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int j = bj * kL0Cols + q * 64 + lane;
+            cv[rr][q] = (i < n && j < n && i < j) ? C[(size_t)i * n + j] : 2.0f;  // 2: never removed, never evaluated
+        }
+    }
+    unsigned long long colbits[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+    {
+        const int r = wave * 16 + rr;
+        const int i = bi * 64 + r;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const int j = bj * kL0Cols + q * 64 + lane;
+            const float c = cv[rr][q];
+            const float ac = fabsf(c);
+            bool rm;
+            if (ac < c_lo)
+                rm = true;
+            else if (ac > c_hi && ac <= 1.0f)
+                rm = false;
+            else
+                rm = (i < n && j < n && i < j) && z_below<false>(c, th);
+            const unsigned long long m = __ballot(rm);
+            if (lane == 0 && m != 0ull)
+            {
+                // Every bitmap word has one owner except those that straddle the diagonal: word (row, w) with
+                // w > row / 64 is decided entirely here (plain store of the complete word), w < row / 64 entirely by
+                // a mirrored tile; only w == row / 64 collects bits from both sides and needs the atomic.  (With a
+                // caller-supplied starting graph the words are not all ones: atomics throughout.)
+                const int w = bj * 4 + q;
+                unsigned long long *dst = &adj[(size_t)i * words + w];
+                if (complete_graph && w != (i >> 6))
+                {
+                    const int valid = n - w * 64;
+                    *dst = ((valid >= 64) ? ~0ull : ((1ull << valid) - 1ull)) & ~m;
+                }
+                else
+                    atomicAnd(dst, ~m);
+            }
+            if (rm) colbits[q] |= (1ull << r);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (colbits[q]) atomicOr(&s_col[q * 64 + lane], colbits[q]);
+    __syncthreads();
+    {
+        const unsigned long long m = s_col[threadIdx.x];
+        const int jj = bj * kL0Cols + threadIdx.x;
+        if (m != 0ull && jj < n)
+        {
+            unsigned long long *dst = &adj[(size_t)jj * words + bi];
+            if (complete_graph && bi != (jj >> 6))
+                *dst = ~m;  // all 64 rows of block bi lie above row jj and exist
+            else
+                atomicAnd(dst, ~m);
+        }
+    }
+}
+
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st)
 {
@@ -118,14 +241,31 @@ hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, un
     const int tiles = words;
     const long long ntile = (long long)tiles * (tiles + 1) / 2;
     const dim3 grid((unsigned)ntile), block(256);
-    if (Ness && asym_flag)
-        hipLaunchKernelGGL((level0_kernel<true, true>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
+    // guard band of the |c| comparison; thresholds below kThMinFilter get an empty fast range (exact everywhere)
+    float c_lo = 0.0f, c_hi = 2.0f;
+    if (th >= kThMinFilter)
+    {
+        const double tq = std::tanh((double)th);
+        c_lo = (float)(tq * (1.0 - 5e-4));
+        c_hi = (float)(tq * (1.0 + 5e-4));
+    }
+    if (!Ness && !asym_flag)
+    {
+        const int col_tiles = (n + kL0Cols - 1) / kL0Cols;
+        long long nt = 0;
+        for (int bi = 0; bi < tiles; bi++) nt += col_tiles - (bi >> 2);
+        hipLaunchKernelGGL(level0_wide_kernel, dim3((unsigned)nt), block, 0, st, C, adj, n, words, th, c_lo, c_hi, col_tiles,
+                           Ginit == nullptr ? 1 : 0);
+    }
+    else if (Ness && asym_flag)
+        hipLaunchKernelGGL((level0_kernel<true, true>), grid, block, 0, st, C, Ness, adj, n, words, th, c_lo, c_hi, tiles,
+                           asym_flag);
     else if (Ness)
-        hipLaunchKernelGGL((level0_kernel<true, false>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
-    else if (asym_flag)
-        hipLaunchKernelGGL((level0_kernel<false, true>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
+        hipLaunchKernelGGL((level0_kernel<true, false>), grid, block, 0, st, C, Ness, adj, n, words, th, c_lo, c_hi, tiles,
+                           asym_flag);
     else
-        hipLaunchKernelGGL((level0_kernel<false, false>), grid, block, 0, st, C, Ness, adj, n, words, th, tiles, asym_flag);
+        hipLaunchKernelGGL((level0_kernel<false, true>), grid, block, 0, st, C, Ness, adj, n, words, th, c_lo, c_hi, tiles,
+                           asym_flag);
     return hipGetLastError();
 }
 
