@@ -189,7 +189,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, cs));
             else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
-                     sweep_vec_lds_bytes(c) <= kLdsLimit)
+                     sweep_vec_lds_bytes(c) <= kLdsLimit && l < kVecMaxLevel)
                 CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, pl.nitems[c], cs));
             else if (pl.use_fast && !exact_only)
                 CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], cs));

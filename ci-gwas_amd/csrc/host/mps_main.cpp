@@ -10,6 +10,7 @@
 // sweep, adjacency comes back as a bitmap, separating sets as sparse records, only the
 // retained sub-matrix is gathered to the host, and files are written with one fwrite each.
 // `mps prep` / `mps block` are outside this build's scope and say so.
+#include <chrono>
 #include <algorithm>
 #include <cstring>
 #include <memory>
@@ -202,6 +203,21 @@ Run the skeleton search on a single block of a block diagonal genomic covariance
 usage: mps cusk <.phen> <bfiles> <.blocks> <alpha> <max-level> <max-level-two> <depth> <outdir> <block-index>
 )";
 
+// wall-clock phase marks, printed as "[t] <phase>: <ms> ms" when CUSK_TIMING is set (tools/e2e_block.py)
+struct PhaseTimer
+{
+    bool on = std::getenv("CUSK_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void mark(const char *what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::cout << "[t] " << what << ": " << std::chrono::duration<double, std::milli>(now - last).count() << " ms (at "
+                  << std::chrono::duration<double, std::milli>(now - t0).count() << ")" << std::endl;
+        last = now;
+    }
+};
+
 int cmd_cusk(int argc, char **argv)
 {
     if (argc < 11)
@@ -220,6 +236,7 @@ int cmd_cusk(int argc, char **argv)
               << "\nalpha: " << alpha << "\nmax_level: " << max_level << "\nmax_level_two: " << max_level_two
               << "\ndepth: " << depth << "\noutdir: " << outdir << "\nblock-index: " << block_index << std::endl;
 
+    PhaseTimer tm;
     std::cout << "Checking paths" << std::endl;
     for (const char *sfx : {".bed", ".dim", ".means", ".stds", ".bim"}) check_path(bfiles + sfx);
     if (!bed_has_valid_magic(bfiles + ".bed")) die("unexpected magic number in bed file.");
@@ -228,6 +245,7 @@ int cmd_cusk(int argc, char **argv)
     check_path(outdir);
 
     Phen phen = load_phen(phen_path);
+    tm.mark("load phen");
     const BedDims dims = read_dims(bfiles + ".dim");
     if (phen.num_samples != dims.num_samples) die("different num samples in phen and dims");
     const BimInfo bim = read_bim(bfiles + ".bim");
@@ -257,18 +275,21 @@ int cmd_cusk(int argc, char **argv)
     const std::vector<float> means = read_floats_line_range(bfiles + ".means", g0, g1);
     const std::vector<float> stds = read_floats_line_range(bfiles + ".stds", g0, g1);
     if (means.size() != m || stds.size() != m) die("block size and number of means or stds differ");
+    tm.mark("bim, blocks, bed block, means, stds");
 
     cusk_engine *e = nullptr;
     if (cusk_engine_create(&e, 0, nullptr) != CUSK_OK) engine_die("engine create (is a HIP device visible?)", nullptr);
     const size_t n = m + p;
     DevMat C(n * n);
     if (!C.p) engine_die("device allocation", e);
+    tm.mark("engine create + device allocation");
 
     std::cout << "Checking for significant marker - phen correlations" << std::endl;
     std::cout << "Computing all correlations" << std::endl;
     std::vector<float> mxp(m * p);
     if (cusk_corr_build(e, bed.data(), phen.data.data(), m, N, p, means.data(), stds.data(), C.p, mxp.data()) != CUSK_OK)
         engine_die("correlation build", e);
+    tm.mark("correlation build (H2D + kernels + mxp D2H)");
     // cli.cpp:561-576: blocks without any marginally significant marker-trait correlation are skipped
     int num_sig = 0;
     for (float c : mxp) num_sig += (std::fabs(0.5 * (std::log(std::fabs((1 + c))) - std::log(std::fabs(1 - c)))) >= Th[0]);
@@ -291,6 +312,7 @@ int cmd_cusk(int argc, char **argv)
     cusk_engine_set_option(e, "assume_symmetric", 1);  // cusk_corr_build mirrors every element
     cusk_stats st;
     if (cusk_run_skeleton(e, C.p, (int)n, Th, max_level, &st) != CUSK_OK) engine_die("Skeleton", e);
+    tm.mark("skeleton stage one");
     for (int l = 0; l < st.levels_run; l++)
         std::cout << "level " << l << ": max degree " << st.max_degree[l] << ", " << st.tests[l] << " tests, "
                   << st.level_ms[l] * 1e-3 << " s" << std::endl;
@@ -302,6 +324,7 @@ int cmd_cusk(int argc, char **argv)
     gcs.max_level = (size_t)max_level;
     gcs.new_to_old = P;
     gcs.C = gather(e, C.p, (int)n, P);
+    tm.mark("adjacency fetch + prune + sub-matrix gather");
     // (the stage-one separating sets of cli.cpp:673 are never read again: stage two recomputes them)
 
     std::cout << "Starting second cusk stage" << std::endl;
@@ -310,6 +333,12 @@ int cmd_cusk(int argc, char **argv)
         DevMat C2(gcs.C);
         cusk_engine_set_option(e, "assume_symmetric", 0);
         if (cusk_run_skeleton(e, C2.p, k, Th, max_level_two, &st) != CUSK_OK) engine_die("Skeleton (stage two)", e);
+        tm.mark("skeleton stage two");
+        if (tm.on)
+            for (int l = 0; l < st.levels_run; l++)
+                std::cout << "[t] stage two level " << l << ": max degree " << st.max_degree[l] << ", " << st.edges[l]
+                          << " edges, " << st.tests[l] << " tests, " << st.subsets[l] << " sets, " << st.rechecks[l]
+                          << " rechecks, sweep " << st.kernel_ms[l] << " ms, level " << st.level_ms[l] << " ms" << std::endl;
         Bits G2 = fetch_adjacency(e);
         std::vector<int> P2 = subset_variables(G2, k, (int)gcs.num_markers(), depth);
         Reduced out;
@@ -321,9 +350,12 @@ int cmd_cusk(int argc, char **argv)
         out.C = gather(e, C2.p, k, P2);
         out.S = reduce_sepsets(e, P2, ML, &gcs.new_to_old);
         std::cout << "Retained " << out.num_markers() << " markers" << std::endl;
+        tm.mark("stage-two reduction");
         write_reduced(out, make_path(outdir, block.file_stem(), ""), true);
+        tm.mark("write outputs");
     }
     cusk_engine_destroy(e);
+    tm.mark("engine destroy");
     return 0;
 }
 

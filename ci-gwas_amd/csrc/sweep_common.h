@@ -5,6 +5,7 @@
 namespace cusk {
 
 constexpr int kBinomStride = 16;        // binom[a * 16 + b] = C(a, b), b <= 15, saturating at 2^62
+constexpr int kVecMaxLevel = 12;  // from here on the float2 sweep kernel spills (the Cholesky factor alone is l(l-1)/2 registers): scalar form
 constexpr float kThMinFilter = 2e-3f;  // smallest Fisher-z threshold the fast filters are certified for
 
 struct RowInfo

@@ -47,6 +47,8 @@ __host__ __device__ inline VecLayout vec_layout(int cap)
     return l;
 }
 
+constexpr int kSplitLevel = 10;  // from this level on the two float2 pairs of a group are evaluated sequentially
+
 template <int L, int MODE>
 __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 {
@@ -172,33 +174,70 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                 }
                 if (livem == 0u) continue;
                 // four tests, evaluated as two float2 pairs
-                f4 my[L];
-#pragma unroll
-                for (int a = 0; a < L; a++) my[a] = *reinterpret_cast<const f4 *>(col[a] + g);
-                const f4 m0 = *reinterpret_cast<const f4 *>(s_rowx + g);
-                f2 bA[L], bB[L];
                 f2 h11A = {1.0f, 1.0f}, h11B = {1.0f, 1.0f};
-                f2 h01A = {m0.x, m0.y}, h01B = {m0.z, m0.w};
-#pragma unroll
-                for (int i = 0; i < L; i++)
+                f2 h01A, h01B;
+                if constexpr (L < kSplitLevel)
                 {
-                    f2 sA = {my[i].x, my[i].y}, sB = {my[i].z, my[i].w};
+                    f4 my[L];
 #pragma unroll
-                    for (int k = 0; k < i; k++)
+                    for (int a = 0; a < L; a++) my[a] = *reinterpret_cast<const f4 *>(col[a] + g);
+                    const f4 m0 = *reinterpret_cast<const f4 *>(s_rowx + g);
+                    f2 bA[L], bB[L];
+                    h01A = f2{m0.x, m0.y};
+                    h01B = f2{m0.z, m0.w};
+#pragma unroll
+                    for (int i = 0; i < L; i++)
                     {
-                        const float fik = fx.f[i * (i - 1) / 2 + k];
-                        const f2 nf = {-fik, -fik};
-                        sA = __builtin_elementwise_fma(nf, bA[k], sA);
-                        sB = __builtin_elementwise_fma(nf, bB[k], sB);
+                        f2 sA = {my[i].x, my[i].y}, sB = {my[i].z, my[i].w};
+#pragma unroll
+                        for (int k = 0; k < i; k++)
+                        {
+                            const float fik = fx.f[i * (i - 1) / 2 + k];
+                            const f2 nf = {-fik, -fik};
+                            sA = __builtin_elementwise_fma(nf, bA[k], sA);
+                            sB = __builtin_elementwise_fma(nf, bB[k], sB);
+                        }
+                        const f2 iv = {fx.invd[i], fx.invd[i]};
+                        bA[i] = sA * iv;
+                        bB[i] = sB * iv;
+                        h11A = __builtin_elementwise_fma(-bA[i], bA[i], h11A);
+                        h11B = __builtin_elementwise_fma(-bB[i], bB[i], h11B);
+                        const f2 na = {-fx.a[i], -fx.a[i]};
+                        h01A = __builtin_elementwise_fma(na, bA[i], h01A);
+                        h01B = __builtin_elementwise_fma(na, bB[i], h01B);
                     }
-                    const f2 iv = {fx.invd[i], fx.invd[i]};
-                    bA[i] = sA * iv;
-                    bB[i] = sB * iv;
-                    h11A = __builtin_elementwise_fma(-bA[i], bA[i], h11A);
-                    h11B = __builtin_elementwise_fma(-bB[i], bB[i], h11B);
-                    const f2 na = {-fx.a[i], -fx.a[i]};
-                    h01A = __builtin_elementwise_fma(na, bA[i], h01A);
-                    h01B = __builtin_elementwise_fma(na, bB[i], h01B);
+                }
+                else
+                {
+                    // deep levels: the factor alone fills most of the register file (L(L-1)/2 + 2L values), so the
+                    // two pairs are evaluated one after the other with 8-byte operand reads (2L live operands and
+                    // 2L substitution results instead of 8L); same arithmetic, same order per test
+                    auto pair_eval = [&](int gofs, f2 &h11, f2 &h01) {
+                        f2 my2[L], b[L];
+#pragma unroll
+                        for (int a = 0; a < L; a++) my2[a] = *reinterpret_cast<const f2 *>(col[a] + g + gofs);
+                        h01 = *reinterpret_cast<const f2 *>(s_rowx + g + gofs);
+#pragma unroll
+                        for (int i = 0; i < L; i++)
+                        {
+                            f2 sv = my2[i];
+#pragma unroll
+                            for (int k = 0; k < i; k++)
+                            {
+                                const float fik = fx.f[i * (i - 1) / 2 + k];
+                                const f2 nf = {-fik, -fik};
+                                sv = __builtin_elementwise_fma(nf, b[k], sv);
+                            }
+                            const f2 iv = {fx.invd[i], fx.invd[i]};
+                            b[i] = sv * iv;
+                            h11 = __builtin_elementwise_fma(-b[i], b[i], h11);
+                            const f2 na = {-fx.a[i], -fx.a[i]};
+                            h01 = __builtin_elementwise_fma(na, b[i], h01);
+                        }
+                    };
+                    pair_eval(0, h11A, h01A);
+                    __builtin_amdgcn_sched_barrier(0);  // keep the second pair's operands out of the first pair's registers
+                    pair_eval(2, h11B, h01B);
                 }
                 const f2 prodA = h00v * h11A, prodB = h00v * h11B;
                 const f2 lhsA = h01A * h01A, lhsB = h01B * h01B;
