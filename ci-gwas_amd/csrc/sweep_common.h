@@ -5,7 +5,7 @@
 namespace cusk {
 
 constexpr int kBinomStride = 16;        // binom[a * 16 + b] = C(a, b), b <= 15, saturating at 2^62
-constexpr int kVecMaxLevel = 12;  // from here on the float2 sweep kernel spills (the Cholesky factor alone is l(l-1)/2 registers): scalar form
+constexpr int kVecMaxLevel = 9;  // measured crossover (10k block, stage two, d = 39): the float2 kernel wins up to level 8, the scalar one (fewer registers, 2-3 waves per SIMD) from level 9; at l = 14 the float2 form spills
 constexpr float kThMinFilter = 2e-3f;  // smallest Fisher-z threshold the fast filters are certified for
 
 struct RowInfo

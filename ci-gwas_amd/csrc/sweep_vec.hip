@@ -133,6 +133,7 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
         {
             const unsigned myrel = (unsigned)(rank - r0) + 1u;  // >= 1: padding and decided entries (0) are never live
             SubsetFast<L> fx;
+            if constexpr (L < kSplitLevel)
             {
                 float cl[SubsetFast<L>::NL], m1x[L];
 #pragma unroll
@@ -143,6 +144,8 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                     for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = s_sub[idx[a] * ld4 + idx[b]];  // C[S_b, S_a]
                 fx.prepare(cl, m1x);
             }
+            else
+                fx.prepare_fetch([&](int a, int b) { return s_sub[idx[a] * ld4 + idx[b]]; }, [&](int a) { return s_rowx[idx[a]]; });
             nsub++;
             [[maybe_unused]] int tmaxS = 0;
             if constexpr (MODE == 1)
@@ -151,9 +154,12 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 #pragma unroll
                 for (int a = 1; a < L; a++) tmaxS = max(tmaxS, s_ti[idx[a]]);
             }
-            const float *col[L];
+            [[maybe_unused]] const float *col[(L < kSplitLevel) ? L : 1];
+            if constexpr (L < kSplitLevel)
+            {
 #pragma unroll
-            for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
+                for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
+            }
             const f2 h00v = {fx.h00, fx.h00};
             bool anyalive = false;
             for (int g = 0; g < dp; g += 4)
@@ -213,14 +219,13 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                     // two pairs are evaluated one after the other with 8-byte operand reads (2L live operands and
                     // 2L substitution results instead of 8L); same arithmetic, same order per test
                     auto pair_eval = [&](int gofs, f2 &h11, f2 &h01) {
-                        f2 my2[L], b[L];
-#pragma unroll
-                        for (int a = 0; a < L; a++) my2[a] = *reinterpret_cast<const f2 *>(col[a] + g + gofs);
+                        f2 b[L];
                         h01 = *reinterpret_cast<const f2 *>(s_rowx + g + gofs);
 #pragma unroll
                         for (int i = 0; i < L; i++)
                         {
-                            f2 sv = my2[i];
+                            // operand read where it is consumed: no array of L pending operands
+                            f2 sv = *reinterpret_cast<const f2 *>(s_sub + idx[i] * ld4 + g + gofs);
 #pragma unroll
                             for (int k = 0; k < i; k++)
                             {
