@@ -80,43 +80,6 @@ struct SubsetFast
         ill = !(dmin >= kCondMin) || !(hh >= kCondMin);
     }
 
-    // same factorisation with the operands fetched where they are consumed (c_of(i, j) = C[S_i, S_j], j < i;
-    // x_of(i) = C[X, S_i]): deep levels cannot afford a register copy of the l(l-1)/2 block next to the factor
-    template <typename FC, typename FX>
-    __device__ __forceinline__ void prepare_fetch(FC c_of, FX x_of)
-    {
-        float dmin = 1.0f;
-#pragma unroll
-        for (int i = 0; i < L; i++)
-        {
-            float dii = 1.0f;
-#pragma unroll
-            for (int j = 0; j < i; j++)
-            {
-                float s = c_of(i, j);
-#pragma unroll
-                for (int k = 0; k < j; k++) s = __builtin_fmaf(-f[i * (i - 1) / 2 + k], f[j * (j - 1) / 2 + k], s);
-                const float lij = s * invd[j];
-                f[i * (i - 1) / 2 + j] = lij;
-                dii = __builtin_fmaf(-lij, lij, dii);
-            }
-            dmin = fminf(dmin, dii);
-            invd[i] = __frsqrt_rn(dii);
-        }
-        float hh = 1.0f;
-#pragma unroll
-        for (int i = 0; i < L; i++)
-        {
-            float s = x_of(i);
-#pragma unroll
-            for (int k = 0; k < i; k++) s = __builtin_fmaf(-f[i * (i - 1) / 2 + k], a[k], s);
-            a[i] = s * invd[i];
-            hh = __builtin_fmaf(-a[i], a[i], hh);
-        }
-        h00 = hh;
-        ill = !(dmin >= kCondMin) || !(hh >= kCondMin);
-    }
-
     // m0 = C[X,Y], m1y = C[Y,S]; returns H01 and H11
     __device__ __forceinline__ void schur(float m0, const float *m1y, float &h01, float &h11) const
     {

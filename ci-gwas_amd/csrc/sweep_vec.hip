@@ -47,8 +47,6 @@ __host__ __device__ inline VecLayout vec_layout(int cap)
     return l;
 }
 
-constexpr int kSplitLevel = 10;  // from this level on the two float2 pairs of a group are evaluated sequentially
-
 template <int L, int MODE>
 __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 {
@@ -133,7 +131,6 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
         {
             const unsigned myrel = (unsigned)(rank - r0) + 1u;  // >= 1: padding and decided entries (0) are never live
             SubsetFast<L> fx;
-            if constexpr (L < kSplitLevel)
             {
                 float cl[SubsetFast<L>::NL], m1x[L];
 #pragma unroll
@@ -144,8 +141,6 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                     for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = s_sub[idx[a] * ld4 + idx[b]];  // C[S_b, S_a]
                 fx.prepare(cl, m1x);
             }
-            else
-                fx.prepare_fetch([&](int a, int b) { return s_sub[idx[a] * ld4 + idx[b]]; }, [&](int a) { return s_rowx[idx[a]]; });
             nsub++;
             [[maybe_unused]] int tmaxS = 0;
             if constexpr (MODE == 1)
@@ -154,12 +149,9 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 #pragma unroll
                 for (int a = 1; a < L; a++) tmaxS = max(tmaxS, s_ti[idx[a]]);
             }
-            [[maybe_unused]] const float *col[(L < kSplitLevel) ? L : 1];
-            if constexpr (L < kSplitLevel)
-            {
+            const float *col[L];
 #pragma unroll
-                for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
-            }
+            for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
             const f2 h00v = {fx.h00, fx.h00};
             bool anyalive = false;
             for (int g = 0; g < dp; g += 4)
@@ -180,69 +172,33 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                 }
                 if (livem == 0u) continue;
                 // four tests, evaluated as two float2 pairs
+                f4 my[L];
+#pragma unroll
+                for (int a = 0; a < L; a++) my[a] = *reinterpret_cast<const f4 *>(col[a] + g);
+                const f4 m0 = *reinterpret_cast<const f4 *>(s_rowx + g);
+                f2 bA[L], bB[L];
                 f2 h11A = {1.0f, 1.0f}, h11B = {1.0f, 1.0f};
-                f2 h01A, h01B;
-                if constexpr (L < kSplitLevel)
+                f2 h01A = {m0.x, m0.y}, h01B = {m0.z, m0.w};
+#pragma unroll
+                for (int i = 0; i < L; i++)
                 {
-                    f4 my[L];
+                    f2 sA = {my[i].x, my[i].y}, sB = {my[i].z, my[i].w};
 #pragma unroll
-                    for (int a = 0; a < L; a++) my[a] = *reinterpret_cast<const f4 *>(col[a] + g);
-                    const f4 m0 = *reinterpret_cast<const f4 *>(s_rowx + g);
-                    f2 bA[L], bB[L];
-                    h01A = f2{m0.x, m0.y};
-                    h01B = f2{m0.z, m0.w};
-#pragma unroll
-                    for (int i = 0; i < L; i++)
+                    for (int k = 0; k < i; k++)
                     {
-                        f2 sA = {my[i].x, my[i].y}, sB = {my[i].z, my[i].w};
-#pragma unroll
-                        for (int k = 0; k < i; k++)
-                        {
-                            const float fik = fx.f[i * (i - 1) / 2 + k];
-                            const f2 nf = {-fik, -fik};
-                            sA = __builtin_elementwise_fma(nf, bA[k], sA);
-                            sB = __builtin_elementwise_fma(nf, bB[k], sB);
-                        }
-                        const f2 iv = {fx.invd[i], fx.invd[i]};
-                        bA[i] = sA * iv;
-                        bB[i] = sB * iv;
-                        h11A = __builtin_elementwise_fma(-bA[i], bA[i], h11A);
-                        h11B = __builtin_elementwise_fma(-bB[i], bB[i], h11B);
-                        const f2 na = {-fx.a[i], -fx.a[i]};
-                        h01A = __builtin_elementwise_fma(na, bA[i], h01A);
-                        h01B = __builtin_elementwise_fma(na, bB[i], h01B);
+                        const float fik = fx.f[i * (i - 1) / 2 + k];
+                        const f2 nf = {-fik, -fik};
+                        sA = __builtin_elementwise_fma(nf, bA[k], sA);
+                        sB = __builtin_elementwise_fma(nf, bB[k], sB);
                     }
-                }
-                else
-                {
-                    // deep levels: the factor alone fills most of the register file (L(L-1)/2 + 2L values), so the
-                    // two pairs are evaluated one after the other with 8-byte operand reads (2L live operands and
-                    // 2L substitution results instead of 8L); same arithmetic, same order per test
-                    auto pair_eval = [&](int gofs, f2 &h11, f2 &h01) {
-                        f2 b[L];
-                        h01 = *reinterpret_cast<const f2 *>(s_rowx + g + gofs);
-#pragma unroll
-                        for (int i = 0; i < L; i++)
-                        {
-                            // operand read where it is consumed: no array of L pending operands
-                            f2 sv = *reinterpret_cast<const f2 *>(s_sub + idx[i] * ld4 + g + gofs);
-#pragma unroll
-                            for (int k = 0; k < i; k++)
-                            {
-                                const float fik = fx.f[i * (i - 1) / 2 + k];
-                                const f2 nf = {-fik, -fik};
-                                sv = __builtin_elementwise_fma(nf, b[k], sv);
-                            }
-                            const f2 iv = {fx.invd[i], fx.invd[i]};
-                            b[i] = sv * iv;
-                            h11 = __builtin_elementwise_fma(-b[i], b[i], h11);
-                            const f2 na = {-fx.a[i], -fx.a[i]};
-                            h01 = __builtin_elementwise_fma(na, b[i], h01);
-                        }
-                    };
-                    pair_eval(0, h11A, h01A);
-                    __builtin_amdgcn_sched_barrier(0);  // keep the second pair's operands out of the first pair's registers
-                    pair_eval(2, h11B, h01B);
+                    const f2 iv = {fx.invd[i], fx.invd[i]};
+                    bA[i] = sA * iv;
+                    bB[i] = sB * iv;
+                    h11A = __builtin_elementwise_fma(-bA[i], bA[i], h11A);
+                    h11B = __builtin_elementwise_fma(-bB[i], bB[i], h11B);
+                    const f2 na = {-fx.a[i], -fx.a[i]};
+                    h01A = __builtin_elementwise_fma(na, bA[i], h01A);
+                    h01B = __builtin_elementwise_fma(na, bB[i], h01B);
                 }
                 const f2 prodA = h00v * h11A, prodB = h00v * h11B;
                 const f2 lhsA = h01A * h01A, lhsB = h01B * h01B;
@@ -363,13 +319,10 @@ hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, long
         CUSK_CASE(6)
         CUSK_CASE(7)
         CUSK_CASE(8)
-        CUSK_CASE(9)
-        CUSK_CASE(10)
-        CUSK_CASE(11)
-        CUSK_CASE(12)
-        CUSK_CASE(13)
-        CUSK_CASE(14)
+        // levels >= kVecMaxLevel (9) run on sweep_fast_kernel: the factor alone is l(l-1)/2 registers there, the
+        // float2 form drops to one wave per SIMD (and spills at l = 14) and loses to the scalar form
 #undef CUSK_CASE
+        static_assert(kVecMaxLevel == 9, "instantiate the levels below kVecMaxLevel");
     }
     return hipErrorInvalidValue;
 }
