@@ -84,6 +84,7 @@ struct cusk_engine
     int *hflag = nullptr;
     std::vector<unsigned long long> binom_host;
     long long binom_rows = 0;  // rows of the device-resident binomial table
+    hipEvent_t ev_cnt = nullptr;  // the level counters have reached the pinned mirror
     hipEvent_t ev_main[2] = {nullptr, nullptr};  // around the level-1 rows kernel alone
     hipEvent_t ev_run[2] = {nullptr, nullptr};
     hipEvent_t ev_k0[cusk::kLevels], ev_k1[cusk::kLevels], ev_l0[cusk::kLevels], ev_l1[cusk::kLevels];

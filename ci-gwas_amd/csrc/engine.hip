@@ -213,11 +213,6 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         CUSK_HIP(e, launch_finalize(l, pl.fp, s, e->opt_overlap ? e->stream2 : s, e->ev_z));
         return CUSK_OK;
     };
-    auto sync_counters = [&]() -> int {
-        CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
-        CUSK_HIP(e, hipStreamSynchronize(s));
-        return CUSK_OK;
-    };
     // a level whose recheck queue overflowed is redone on the exact path (everything the fast
     // pass recorded is a certified verdict and stays valid); returns 1 when it had to
     auto redo_if_overflowed = [&](int l) -> int {
@@ -241,13 +236,45 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         bool rebuilt = false;
         for (;;)
         {
-            CUSK_HIP(e, launch_scan_degrees(e->deg.as<int>(), e->off[cs].as<int>(), n, dcnt + l, s));
-            if (l == 1 && !rebuilt)
+            // which classes can be staged in LDS in this mode
+            int staged_classes = 0;
+            while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
+                staged_classes++;
+            const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+            LevelPlan &pl = plan[l];
+            pl.redone = false;
+            const bool first_build = (l == 1 && !rebuilt);
+            if (rebuilt)  // the plan accumulates its totals with atomics: start from zero again
+                CUSK_HIP(e, hipMemsetAsync(dcnt + l, 0, sizeof(LevelCounters), s));
+            // 1. the plan of the level from the degrees alone; its counters start their way to the host at once ...
+            //    (level 1 is planned for the generic kernels: whether the matrix is symmetric is only known with
+            //    this read-back, and the row-streaming kernel does not use work items)
+            bool pair_items = (l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows;
+            CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
+                                    e->binom.as<unsigned long long>(), chunk,
+                                    staged_classes, pair_items ? 1 : 0, dcnt + l, s));
+            if (first_build) CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipEventRecord(e->ev_cnt, s));
+            auto build_lists = [&]() -> int {
+                pl.use_fast = (e->opt_fast != 0) && (l >= 2);
+                CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
+                                            (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
+                                            a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words,
+                                            pl.use_rows ? e->wpre.as<int>() : nullptr, s));
+                return CUSK_OK;
+            };
+            // 2. ... while the device already compacts the neighbour lists (nothing there depends on the host),
+            if (!first_build)
+            {
+                int rc = build_lists();
+                if (rc != CUSK_OK) return rc;
+            }
+            // 3. the level's one host round trip: wait for the counters only, not for the stream
+            CUSK_HIP(e, hipEventSynchronize(e->ev_cnt));
+            if (first_build)
             {
                 // sizes of the CSR arrays and of the binomial table come from the level-1 degrees
-                CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
-                int rc = sync_counters();
-                if (rc != CUSK_OK) return rc;
                 symmetric = (*e->hflag == 0) || (e->opt_assume_symmetric != 0);
                 cap_edges = std::max<long long>(e->hcnt[1].total_edges, 1);
                 const int maxdeg1 = e->hcnt[1].maxdeg;
@@ -281,31 +308,19 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                                                e->binom_host.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, s));
                     e->binom_rows = rows;
                 }
+                // level 1 on a symmetric matrix with a single threshold: row-streaming kernel (or the pair kernel)
+                pl.pair_lds = (size_t)e->hcnt[1].maxdeg * 20 + 16;
+                pl.use_pair = !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
+                pl.use_rows = !het && symmetric && (e->opt_pair != 0) && (e->opt_rows != 0);
+                if (pl.use_rows) CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
+                if (pl.use_pair && !pl.use_rows)
+                {  // the pair kernel counts its work items differently: plan again (option rows = 0 only)
+                    rebuilt = true;
+                    continue;
+                }
+                int rc = build_lists();
+                if (rc != CUSK_OK) return rc;
             }
-            // which classes can be staged in LDS in this mode
-            int staged_classes = 0;
-            while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
-                staged_classes++;
-            const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
-            LevelPlan &pl = plan[l];
-            pl.redone = false;
-            // level 1 on a symmetric matrix with a single threshold: pair kernel
-            const int maxdeg_bound = (l == 1) ? e->hcnt[1].maxdeg : local.max_degree[l - 1];
-            pl.pair_lds = (size_t)maxdeg_bound * 20 + 16;
-            pl.use_pair = (l == 1) && !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
-            pl.use_rows = (l == 1) && !het && symmetric && (e->opt_pair != 0) && (e->opt_rows != 0);
-            if (pl.use_rows) CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
-            pl.use_fast = (e->opt_fast != 0) && (l >= 2);
-            if (rebuilt)  // item_scan accumulates the class totals with atomics: start from zero again
-                CUSK_HIP(e, hipMemsetAsync(&dcnt[l].class_items[0], 0, sizeof(long long) * kNumClasses, s));
-            CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
-                                        (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
-                                        a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words, l,
-                                        e->binom.as<unsigned long long>(), chunk, staged_classes, pl.use_pair ? 1 : 0,
-                                        e->rowinfo[cs].as<RowInfo>(), dcnt + l, pl.use_rows ? e->wpre.as<int>() : nullptr, s));
-            CUSK_HIP(e, launch_item_scan(e->rowinfo[cs].as<RowInfo>(), n, dcnt + l, s));
-            int rc = sync_counters();  // the level's one host synchronisation
-            if (rc != CUSK_OK) return rc;
             // did the previous level's recheck queue overflow?  then redo it and rebuild this level
             const int redo = redo_if_overflowed(l - 1);
             if (redo < 0) return -redo;
@@ -510,6 +525,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;
     for (auto &ev : e->ev_run) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (auto &ev : e->ev_main) ok = ok && hipEventCreate(&ev) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&e->ev_cnt, hipEventDisableTiming) == hipSuccess;
     for (auto &ev : e->ev_corr) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int l = 0; l < kLevels; l++)
     {
@@ -545,6 +561,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : e->ev_main)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->ev_cnt) (void)hipEventDestroy(e->ev_cnt);
     for (auto &ev : e->ev_corr)
         if (ev) (void)hipEventDestroy(ev);
     for (int l = 0; l < kLevels; l++)

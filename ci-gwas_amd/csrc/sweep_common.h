@@ -158,11 +158,10 @@ size_t sweep_vec_lds_bytes(int cls);
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st);
 hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
-hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
-                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre, hipStream_t st);
-hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st);
+                           int n, int words, int *wpre, hipStream_t st);
+hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, hipStream_t st);
 hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
                                  hipStream_t st);

@@ -290,101 +290,9 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
     return hipGetLastError();
 }
 
-// Exclusive scan of n ints by ONE workgroup of 1024 threads without serial dependent loads: the array is cut
-// into tiles of 1024 consecutive elements, thread t owns element t of every tile (coalesced), all tiles are
-// requested at once (one memory round trip), scanned across the wave by shuffles, and one barrier exchanges the
-// wave totals of all tiles.  kScanTiles tiles (64k elements) per round, rounds chained through a carry.
-constexpr int kScanTiles = 16;
-
-template <typename Emit>
-__device__ __forceinline__ void block_scan_1024(const int *__restrict__ in, int n, long long *s_tot, int *total_max,
-                                                long long *total_sum, Emit emit)
-{
-    // s_tot: [kScanTiles][16] wave totals
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    long long carry = 0;
-    int mx = 0;
-    for (int r0 = 0; r0 < n; r0 += kScanTiles * 1024)
-    {
-        int v[kScanTiles], incl[kScanTiles];
-#pragma unroll
-        for (int t = 0; t < kScanTiles; t++)
-        {
-            const int i = r0 + t * 1024 + tid;
-            v[t] = (i < n) ? in[i] : 0;
-        }
-#pragma unroll
-        for (int t = 0; t < kScanTiles; t++)
-        {
-            mx = max(mx, v[t]);
-            int x = v[t];
-            for (int o = 1; o < 64; o <<= 1)
-            {
-                const int y = __shfl_up(x, o);
-                if (lane >= o) x += y;
-            }
-            incl[t] = x;
-            if (lane == 63) s_tot[t * 16 + wave] = x;
-        }
-        __syncthreads();
-        long long run = carry;
-#pragma unroll
-        for (int t = 0; t < kScanTiles; t++)
-        {
-            long long before = 0, all = 0;
-#pragma unroll
-            for (int w = 0; w < 16; w++)
-            {
-                const long long c = s_tot[t * 16 + w];
-                if (w < wave) before += c;
-                all += c;
-            }
-            const int i = r0 + t * 1024 + tid;
-            if (i < n) emit(i, run + before + incl[t] - v[t]);
-            run += all;
-        }
-        carry = run;
-        __syncthreads();
-    }
-    // maximum over the block
-    for (int o = 32; o > 0; o >>= 1) mx = max(mx, __shfl_xor(mx, o));
-    if (lane == 0) s_tot[wave] = mx;
-    __syncthreads();
-    if (tid == 0)
-    {
-        int m2 = 0;
-        for (int w = 0; w < 16; w++) m2 = max(m2, (int)s_tot[w]);
-        *total_max = m2;
-        *total_sum = carry;
-    }
-}
-
-// single workgroup: off = exclusive scan of the degrees; total edges and maximum degree of the level
-__global__ void __launch_bounds__(1024) scan_degrees_kernel(const int *deg, int *off, int n, LevelCounters *cnt)
-{
-    __shared__ long long s_tot[kScanTiles * 16];
-    __shared__ int s_max;
-    __shared__ long long s_sum;
-    block_scan_1024(deg, n, s_tot, &s_max, &s_sum, [&](int i, long long e) { off[i] = (int)e; });
-    if (threadIdx.x == 0)
-    {
-        off[n] = (int)s_sum;
-        cnt->total_edges = s_sum;
-        cnt->maxdeg = s_max;
-    }
-}
-
-hipError_t launch_scan_degrees(const int *deg, int *off, int n, LevelCounters *cnt, hipStream_t st)
-{
-    hipLaunchKernelGGL(scan_degrees_kernel, dim3(1), dim3(1024), 0, st, deg, off, n, cnt);
-    return hipGetLastError();
-}
-
-// one wave per row: ascending neighbour indices, reset of the row's selection state, work-item count
+// one wave per row: ascending neighbour indices, reset of the row's selection state
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
-                                unsigned long long *best, int *rowfound, int n, int words, int L,
-                                const unsigned long long *__restrict__ binom, unsigned long long chunk,
-                                int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre)
+                                unsigned long long *best, int *rowfound, int n, int words, int *wpre)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -415,58 +323,108 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
         }
         run += __shfl(incl, 63);
     }
-    if (lane == 0)
-    {
-        const int d = run;
-        RowInfo ri;
-        ri.cls = -1;
-        ri.base = 0;
-        ri.nchunks = 0;
-        ri.pad = 0;
-        if (rowfound) rowfound[row] = 0;
-        if (d > L)
-        {
-            // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
-            const unsigned long long nc =
-                pair_mode ? (unsigned long long)d * (d - 1) / 2 : binom[(size_t)d * kBinomStride + L];
-            if (nc >= (1ull << 62))
-                cnt->overflow = 1;
-            else
-            {
-                int cls = 0;
-                while (d > kClassCap[cls]) cls++;
-                if (cls >= staged_classes) cls = kNumClasses - 1;
-                ri.cls = cls;
-                ri.nchunks = (int)((nc + chunk - 1) / chunk);
-            }
-        }
-        rowinfo[row] = ri;
-    }
+    if (lane == 0 && rowfound) rowfound[row] = 0;
 }
 
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int L, const unsigned long long *binom, unsigned long long chunk,
-                           int staged_classes, int pair_mode, RowInfo *rowinfo, LevelCounters *cnt, int *wpre, hipStream_t st)
+                           int n, int words, int *wpre, hipStream_t st)
 {
-    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, L, binom,
-                       chunk, staged_classes, pair_mode, rowinfo, cnt, wpre);
+    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, wpre);
     return hipGetLastError();
 }
 
-// Places every row's work items inside its class list.  256 rows per workgroup: block-level
-// exclusive scans of the rows' item counts (one per class), then one atomicAdd per class and
-// workgroup reserves the block's range (order between workgroups is irrelevant: items of a class
-// are independent).  class_items[] ends up holding the class totals.
-__global__ void __launch_bounds__(256) item_scan_kernel(RowInfo *rowinfo, int n, LevelCounters *cnt)
+// Exclusive prefix of in[0..n) for the 256 rows of this workgroup, without a second kernel and without atomics:
+// the workgroup first sums everything that lies before its block (redundantly with its peers: block b reads 256 b
+// values, 40 loads per thread at 10k rows), then scans its own 256 values.  Returns the thread's exclusive prefix;
+// *block_total receives the sum over the workgroup's own rows.  s_red: 8 long longs of LDS.
+__device__ __forceinline__ long long prefix_256(const int *__restrict__ in, int n, int v, long long *s_red, long long *block_total)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int first = blockIdx.x * 256;
+    long long before = 0;
+    for (int i0 = 0; i0 < first; i0 += 256 * 16)
+    {  // sixteen independent loads in flight per thread
+        int t[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++)
+        {
+            const int i = i0 + u * 256 + tid;
+            t[u] = (i < first) ? in[i] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) before += t[u];
+    }
+    int incl = v;
+    for (int o = 1; o < 64; o <<= 1)
+    {
+        const int t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    for (int o = 32; o > 0; o >>= 1) before += __shfl_xor(before, o);
+    if (lane == 63) s_red[wave] = incl;
+    if (lane == 0) s_red[4 + wave] = before;
+    __syncthreads();
+    long long pre = s_red[4] + s_red[5] + s_red[6] + s_red[7];
+    for (int w = 0; w < wave; w++) pre += s_red[w];
+    *block_total = s_red[0] + s_red[1] + s_red[2] + s_red[3];
+    (void)n;
+    return pre + incl - v;
+}
+
+// The level's work plan, from the degrees alone (so it can run, and its counters travel to the host, before
+// the neighbour lists are even written): class and work-item count of every row, placement of the items inside
+// the class lists, level totals.  256 rows per workgroup: block-level exclusive scans of the rows' item counts (one
+// per class), then one atomicAdd per class and workgroup reserves the block's range (order between workgroups is
+// irrelevant: items of a class are independent).  class_items[] ends up holding the class totals.
+__global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, int *off, RowInfo *rowinfo, int n, int L,
+                                                     const unsigned long long *__restrict__ binom, unsigned long long chunk,
+                                                     int staged_classes, int pair_mode, LevelCounters *cnt)
 {
     __shared__ int s_wave[kNumClasses][4];
     __shared__ long long s_base[kNumClasses];
+    __shared__ long long s_red[8];
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RowInfo ri;
     ri.cls = -1;
+    ri.base = 0;
     ri.nchunks = 0;
-    if (row < n) ri = rowinfo[row];
+    ri.pad = 0;
+    const int d = (row < n) ? deg[row] : 0;
+    if (d > L)
+    {
+        // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
+        const unsigned long long nc = pair_mode ? (unsigned long long)d * (d - 1) / 2
+                                                : (L == 1 ? (unsigned long long)d : binom[(size_t)d * kBinomStride + L]);
+        if (nc >= (1ull << 62))
+            cnt->overflow = 1;
+        else
+        {
+            int cls = 0;
+            while (d > kClassCap[cls]) cls++;
+            if (cls >= staged_classes) cls = kNumClasses - 1;
+            ri.cls = cls;
+            ri.nchunks = (int)((nc + chunk - 1) / chunk);
+        }
+    }
+    // CSR offsets of the level (exclusive prefix of the degrees); the last workgroup knows the edge total
+    {
+        long long block_total;
+        const long long o0 = prefix_256(deg, n, d, s_red, &block_total);
+        if (row < n) off[row] = (int)o0;
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
+        {
+            const long long total = s_red[4] + s_red[5] + s_red[6] + s_red[7] + block_total;
+            off[n] = (int)total;
+            cnt->total_edges = total;
+        }
+    }
+    // maximum degree: one atomic per wave (160 per launch at 10k rows)
+    {
+        int dmax = d;
+        for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+        if (lane == 0 && dmax > 0) atomicMax(&cnt->maxdeg, dmax);
+    }
     int excl[kNumClasses];
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
@@ -489,6 +447,7 @@ __global__ void __launch_bounds__(256) item_scan_kernel(RowInfo *rowinfo, int n,
         s_base[c] = tot ? (long long)atomicAdd((unsigned long long *)&cnt->class_items[c], (unsigned long long)tot) : 0;
     }
     __syncthreads();
+    if (row < n && ri.cls < 0) rowinfo[row] = ri;
     if (row < n && ri.cls >= 0)
     {
         int add = 0;
@@ -502,9 +461,11 @@ __global__ void __launch_bounds__(256) item_scan_kernel(RowInfo *rowinfo, int n,
     }
 }
 
-hipError_t launch_item_scan(RowInfo *rowinfo, int n, LevelCounters *cnt, hipStream_t st)
+hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, hipStream_t st)
 {
-    hipLaunchKernelGGL(item_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowinfo, n, cnt);
+    hipLaunchKernelGGL(plan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, deg, off, rowinfo, n, L, binom, chunk,
+                       staged_classes, pair_mode, cnt);
     return hipGetLastError();
 }
 
@@ -530,25 +491,28 @@ hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, 
     return hipGetLastError();
 }
 
-// single workgroup: recoff = exclusive scan of rowfound; level total; rec_base[level+1]
-__global__ void __launch_bounds__(1024) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
-                                                         long long *rec_base, int level)
+// recoff = exclusive prefix of rowfound (256 rows per workgroup, prefix_256); level total; rec_base[level+1]
+__global__ void __launch_bounds__(256) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
+                                                        long long *rec_base, int level)
 {
-    __shared__ long long s_tot[kScanTiles * 16];
-    __shared__ int s_max;
-    __shared__ long long s_sum;
-    block_scan_1024(rowfound, n, s_tot, &s_max, &s_sum, [&](int i, long long e) { recoff[i] = (int)e; });
-    if (threadIdx.x == 0)
+    __shared__ long long s_red[8];
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    const int v = (row < n) ? rowfound[row] : 0;
+    long long block_total;
+    const long long e = prefix_256(rowfound, n, v, s_red, &block_total);
+    if (row < n) recoff[row] = (int)e;
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
     {
-        cnt->rec_total = (unsigned long long)s_sum;
-        rec_base[level + 1] = rec_base[level] + s_sum;
+        const long long total = s_red[4] + s_red[5] + s_red[6] + s_red[7] + block_total;
+        cnt->rec_total = (unsigned long long)total;
+        rec_base[level + 1] = rec_base[level] + total;
     }
 }
 
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st)
 {
-    hipLaunchKernelGGL(rec_scan_kernel, dim3(1), dim3(1024), 0, st, rowfound, recoff, n, cnt, rec_base, level);
+    hipLaunchKernelGGL(rec_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowfound, recoff, n, cnt, rec_base, level);
     return hipGetLastError();
 }
 

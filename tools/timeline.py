@@ -2,7 +2,7 @@
 import sqlite3, sys
 c = sqlite3.connect(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof/r_results.db")
 rows = c.execute("select name,start,end,stream_id from kernels order by start").fetchall()
-idx = [i for i, r in enumerate(rows) if "level0_kernel" in r[0]]
+idx = [i for i, r in enumerate(rows) if "level0_" in r[0]]
 i0, i1 = idx[-2], idx[-1]
 t0 = rows[i0][1]
 prev_end = t0
