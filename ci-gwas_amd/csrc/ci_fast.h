@@ -80,6 +80,47 @@ struct SubsetFast
         ill = !(dmin >= kCondMin) || !(hh >= kCondMin);
     }
 
+    // Incremental form: rows >= first of the factor (and of a) are recomputed, the others are kept from the
+    // previous conditioning set, which shares its first `first` members with this one (lexicographic successor).
+    // Row i of F and a[i] depend on S_0..S_i only, so the kept rows are exactly what a full factorisation would
+    // give; operands are fetched where they are consumed (c_of(i, j) = C[S_i, S_j], j < i; x_of(i) = C[X, S_i]).
+    // The pivot guard is read off the stored reciprocal square roots (d_ii >= 1/64  <=>  1/sqrt(d_ii) <= 8).
+    template <typename FC, typename FX>
+    __device__ __forceinline__ void prepare_rows(int first, FC c_of, FX x_of)
+    {
+#pragma unroll
+        for (int i = 0; i < L; i++)
+        {
+            if (i < first) continue;
+            float dii = 1.0f;
+#pragma unroll
+            for (int j = 0; j < i; j++)
+            {
+                float s = c_of(i, j);
+#pragma unroll
+                for (int k = 0; k < j; k++) s = __builtin_fmaf(-f[i * (i - 1) / 2 + k], f[j * (j - 1) / 2 + k], s);
+                const float lij = s * invd[j];
+                f[i * (i - 1) / 2 + j] = lij;
+                dii = __builtin_fmaf(-lij, lij, dii);
+            }
+            invd[i] = __frsqrt_rn(dii);
+            float s = x_of(i);
+#pragma unroll
+            for (int k = 0; k < i; k++) s = __builtin_fmaf(-f[i * (i - 1) / 2 + k], a[k], s);
+            a[i] = s * invd[i];
+        }
+        float hh = 1.0f;
+        bool bad = false;
+#pragma unroll
+        for (int i = 0; i < L; i++)
+        {
+            hh = __builtin_fmaf(-a[i], a[i], hh);
+            bad = bad || !(invd[i] <= 8.0f);
+        }
+        h00 = hh;
+        ill = bad || !(hh >= kCondMin);
+    }
+
     // m0 = C[X,Y], m1y = C[Y,S]; returns H01 and H11
     __device__ __forceinline__ void schur(float m0, const float *m1y, float &h01, float &h11) const
     {

@@ -10,8 +10,11 @@
 
 namespace cusk {
 
+// Register budget by measurement (10k block, stage two): four waves per SIMD (<= 128 VGPRs) up to level 12, three
+// (<= 168) for 13 and 14 -- the deepest level sits just above that line on its own and the third wave is worth more
+// than the handful of spilled values (3.1 s instead of 4.4 s), a fourth would spill the factor (16.7 s).
 template <int L, int MODE, bool HET, bool STAGED, bool VALIDATE>
-__global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L <= 12 ? 4 : 3))) sweep_fast_kernel(SweepParams p)
 {
     static_assert(L >= 2, "level 1 has its own kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -28,17 +31,17 @@ __global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
     {
         int idx[L];
         unrank_comb<L>(rr.lo, d, p.binom, idx);
+        SubsetFast<L> fx;
+        int changed = 0;  // first member that differs from the previous set of this lane: rows before it are kept
         for (unsigned long long rank = rr.lo; rank < rr.hi; rank++)
         {
-            float cl[SubsetFast<L>::NL], m1x[L];
+            [[maybe_unused]] float m1x[L];
+            if constexpr (VALIDATE)
+            {
 #pragma unroll
-            for (int a = 0; a < L; a++) m1x[a] = rv.cval(d, idx[a]);
-#pragma unroll
-            for (int a = 1; a < L; a++)
-#pragma unroll
-                for (int b = 0; b < a; b++) cl[a * (a - 1) / 2 + b] = rv.cval(idx[b], idx[a]);
-            SubsetFast<L> fx;
-            fx.prepare(cl, m1x);
+                for (int a = 0; a < L; a++) m1x[a] = rv.cval(d, idx[a]);
+            }
+            fx.prepare_rows(changed, [&](int a, int b) { return rv.cval(idx[b], idx[a]); }, [&](int a) { return rv.cval(d, idx[a]); });
             nsub++;
             [[maybe_unused]] SubsetExact<L> cx;
             if constexpr (VALIDATE)
@@ -133,7 +136,8 @@ __global__ void __launch_bounds__(kThreads) sweep_fast_kernel(SweepParams p)
                 }
             }
             if (!anyalive) break;
-            if (!next_comb<L>(idx, d)) break;
+            changed = next_comb_pos<L>(idx, d);
+            if (changed < 0) break;
         }
     }
     flush_counters(s_cnt, p.slots, ntests, nsub, nrem, nbad);

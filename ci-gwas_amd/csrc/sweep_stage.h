@@ -190,6 +190,31 @@ __device__ __forceinline__ bool next_comb(int *idx, int d)
     return true;
 }
 
+// the same step with static register indexing only, returning the first position that changed (-1 at the end):
+// consecutive combinations share everything before that position (the incremental factorisation relies on it)
+template <int L>
+__device__ __forceinline__ int next_comb_pos(int (&idx)[L], int d)
+{
+    int pos = -1;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+        if (idx[i] < d - L + i) pos = i;
+    if (pos < 0) return -1;
+    int base = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        if (i == pos)
+        {
+            idx[i]++;
+            base = idx[i];
+        }
+        else if (i > pos)
+            idx[i] = base + (i - pos);
+    }
+    return pos;
+}
+
 // workgroup-level flush of the per-lane counters into the level's spread slots
 __device__ __forceinline__ void flush_counters(unsigned long long *s_cnt, unsigned long long *slots, unsigned long long a,
                                                unsigned long long b, unsigned long long c, unsigned long long dd)
