@@ -226,3 +226,25 @@ def synth_corr_block_torch(m: int, p: int, N: int = 16384, block_index: int = 0,
     Cm = Cm + Cm.T
     Cm.fill_diagonal_(1.0)
     return Cm
+
+
+def hub_corr(nleaf: int, nhub: int, seed: int, noise: float = 1.0) -> np.ndarray:
+    """Population correlation matrix of `nleaf` nearly independent variables and `nhub` hubs, each a random signed
+    combination of ALL leaves plus noise.  A hub stays adjacent to every leaf whatever is conditioned on (the edges are
+    real), so the skeleton keeps a degree of nleaf + nhub - 1 to the deepest level: the matrix that drives the sweep
+    through levels 9..14 in the tests (level l of a hub row enumerates C(nleaf + nhub - 1, l) conditioning sets)."""
+    rng = np.random.default_rng(seed)
+    n = nleaf + nhub
+    A = np.eye(nleaf) + 0.02 * rng.normal(size=(nleaf, nleaf))
+    SL = A @ A.T
+    W = rng.uniform(0.5, 1.0, size=(nhub, nleaf)) * rng.choice([-1.0, 1.0], size=(nhub, nleaf))
+    S = np.zeros((n, n))
+    S[:nleaf, :nleaf] = SL
+    S[nleaf:, :nleaf] = W @ SL
+    S[:nleaf, nleaf:] = S[nleaf:, :nleaf].T
+    S[nleaf:, nleaf:] = W @ SL @ W.T + noise * np.eye(nhub)
+    d = np.sqrt(np.diag(S))
+    C = (S / d[:, None] / d[None, :]).astype(np.float32)
+    C = np.minimum(C, C.T)
+    np.fill_diagonal(C, 1.0)
+    return np.ascontiguousarray(C)

@@ -81,6 +81,29 @@ def test_skeleton_dense_high_levels(cg, eng, oracle, synth):
     assert st.level >= 5
 
 
+@pytest.mark.parametrize("nleaf,nhub,fast", [(16, 3, 1), (17, 3, 1), (15, 2, 0)])
+def test_skeleton_deepest_levels(cg, oracle, synth, nleaf, nhub, fast):
+    """hubs adjacent to every leaf keep their degree to the end: all of levels 1..14 run (float2 filter kernel up to
+    level 8, scalar filter kernel with the incremental factorisation from level 9, SVD exact path for the rechecks
+    and the winners' z), bit-exact against the oracle; fast = 0 is the exact arithmetic everywhere"""
+    Cm = synth.hub_corr(nleaf, nhub, seed=4)
+    Th = cg.threshold_array(20000, 0.01)
+    e = cg.Engine(0)
+    e.set_option("fast", fast)
+    st, ref = _check_skeleton(cg, e, oracle, Cm, Th, 14)
+    assert st.levels_run == 15 and ref.level == 15 and all(t > 0 for t in st.tests[9:15])
+    # and through the hetcor engine (uniform effective sample size): adjacency only
+    n = nleaf + nhub
+    th = cg.hetcor_threshold(0.01)
+    ti = np.zeros(n, np.int32)
+    ref2 = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), 20000, np.float32), th, 14, ti)
+    Cd = cg.DeviceArray(Cm)
+    st2 = e.run_hetcor(Cd.ptr, n, th, 14, ess_uniform=20000.0, time_index=ti)
+    assert st2.level == ref2.level and np.array_equal(e.adjacency(), ref2.G)
+    Cd.free()
+    e.close()
+
+
 @pytest.mark.parametrize("m,p,maxlevel", [(400, 6, 3), (800, 10, 5)])
 def test_skeleton_ld_block(cg, eng, oracle, synth, m, p, maxlevel):
     Cm = synth.synth_corr_block(m, p, N=4096, block_index=m)
