@@ -22,7 +22,7 @@ def test_config3_cuskss_50k_properties(oracle, synth):
 
     import cigwas_amd as cg
 
-    m, p, N, alpha, lmax = 50000, 20, 16384, 1e-4, 2
+    m, p, N, alpha, lmax = 50000, 20, 16384, 1e-4, 5
     n = m + p
     Ct = synth.synth_corr_block_torch(m, p, N, block_index=3)
     torch.cuda.synchronize()
@@ -78,7 +78,7 @@ def test_config5_cuskss_het_30k_properties(oracle, synth):
 
     import cigwas_amd as cg
 
-    m, p, N, alpha, lmax = 30000, 15, 16384, 1e-4, 2
+    m, p, N, alpha, lmax = 30000, 15, 16384, 1e-4, 5
     n = m + p
     Ct = synth.synth_corr_block_torch(m, p, N, block_index=5)
     g = torch.Generator(device="cuda")
