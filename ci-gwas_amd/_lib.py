@@ -55,6 +55,8 @@ SYMBOLS = {
     "cusk_result_sepsets": (_ll, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cusk_corr_build": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
     "cusk_corr_timing": (None, [_vp, _vp]),
+    "cusk_corr_banded": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
+    "cusk_hanning_smooth": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
     "cusk_gather_submatrix": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "cusk_dev_alloc": (_vp, [_sz]),
     "cusk_dev_free": (None, [_vp]),

@@ -2,7 +2,7 @@
 """`ci-gwas.py`-compatible command line for the cusk path on MI355X.
 
 Mirrors the reference's workflow CLI for the two GPU subcommands
-(/root/reference/ci-gwas.py:64-93 `cusk`, :95-253 `cuskss`, handlers :404-456): same
+(/root/reference/ci-gwas.py:63-92 `block`, :64-93 `cusk`, :95-253 `cuskss`, handlers :404-456): same
 positional / optional arguments, same range checks, same conversion to the positional argv of
 the native `mps` program with literal 'NULL' for absent paths, `subprocess.run(check=True)`.
 `cuskss-het` and `cuskss-merged` (README.md:65,75 of the reference names them, its CLI does
@@ -59,6 +59,19 @@ def _add_cusk(sub):
     p.set_defaults(func=cusk)
 
 
+def _add_block(sub):
+    """ci-gwas.py:63-92"""
+    p = sub.add_parser("block", help="Tile whole-genome LD matrix into block diagonal matrix (requires GPU)")
+    p.add_argument("bfiles", type=str, help="filestem of .bed, .bim, .fam fileset")
+    p.add_argument("max_block_size", metavar="max-block-size", help="maximum number of markers per block", default=11000,
+                   type=TypeCheck(int, "max-block-size", 2, None))
+    p.add_argument("device_mem_gb", metavar="device-mem-gb", help="maximum memory available on GPU in GB", default=10,
+                   type=TypeCheck(int, "device-mem-gb", 0, None))
+    p.add_argument("corr_width", metavar="corr-width", help="width of banded-correlation matrix", default=2000,
+                   type=TypeCheck(int, "corr-width", 2, None))
+    p.set_defaults(func=block)
+
+
 def _add_cuskss(sub, name, help_):
     p = sub.add_parser(name, help=help_)
     p.add_argument("--mxm", type=str, default="NULL")
@@ -82,11 +95,21 @@ def _add_cuskss(sub, name, help_):
 def build_parser() -> argparse.ArgumentParser:
     parser = _Parser(prog="ci-gwas", description="cusk / cuskss steps of CI-GWAS on AMD Instinct MI355X")
     sub = parser.add_subparsers(required=True, title="subcommands")
+    _add_block(sub)
     _add_cusk(sub)
     _add_cuskss(sub, "cuskss", "Infer skeleton using summary statistic data (requires GPU)")
     _add_cuskss(sub, "cuskss-het", "cuskss with heterogeneous (polychoric/polyserial) correlations: needs --mxp-se/--pxp-se")
     _add_cuskss(sub, "cuskss-merged", "cuskss on the union of markers selected in all blocks: needs --marker-indices")
     return parser
+
+
+def block_argv(args) -> list[str]:
+    """ci-gwas.py `block` handler"""
+    return [MPS_PATH, "block", args.bfiles, str(args.max_block_size), str(args.device_mem_gb), str(args.corr_width)]
+
+
+def block(args):
+    subprocess.run(block_argv(args), check=True)
 
 
 def cusk_argv(args) -> list[str]:

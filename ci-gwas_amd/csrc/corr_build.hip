@@ -369,13 +369,17 @@ typedef float v16f __attribute__((ext_vector_type(16)));
 constexpr int kKB4 = 256;        // individuals per K block
 constexpr int kKS4 = kKB4 / 64;  // MFMA steps per K block
 
+// band_w = 0: square output C[n x n], both triangles, upper-triangle tiles enumerated along blockIdx.x.
+// band_w > 0 (mps block): banded output C[i * band_w + (j - i - 1)] for 0 < j - i <= band_w, tile (blockIdx.x,
+// blockIdx.x + blockIdx.y).
 template <bool FAST>
 __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__restrict__ bed, float *C, size_t m, size_t N,
-                                                          size_t clb, size_t n, int tiles)
+                                                          size_t clb, size_t n, int tiles, size_t band_w)
 {
     __shared__ v4i sA[3][kKS4][2][kMT];
     __shared__ v4i sB[3][kKS4][2][kMT];
     int t = blockIdx.x, bi = 0;
+    if (band_w == 0)
     {
         int rem = t, len = tiles;
         while (rem >= len)
@@ -385,6 +389,12 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
             bi++;
         }
         t = bi + rem;
+    }
+    else
+    {
+        bi = blockIdx.x;
+        t = bi + (int)blockIdx.y;
+        if (t >= tiles) return;
     }
     const int bj = t;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -587,10 +597,14 @@ __global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__
             s[2] = (float)(nv2 - n12 - n22);
             s[0] = (float)(nvv - n1v - n2v - (nv1 - n11 - n21) - (nv2 - n12 - n22));
             r = npn_from_counts(s);
-            C[i * n + j] = r;
+            if (band_w == 0)
+                C[i * n + j] = r;
+            else if (j - i - 1 < band_w)
+                C[i * band_w + (j - i - 1)] = r;
         }
         scratch[cl * 33 + rl] = r;
     }
+    if (band_w != 0) return;  // no mirrored triangle in the banded layout (uniform per launch)
     __syncthreads();
 #pragma unroll
     for (int e = 0; e < 16; e++)
@@ -965,10 +979,10 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 15u) == 0);
         if (e->opt_corr_fp4 && rows16)
             hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
-                               m, N, clb, n, tiles);
+                               m, N, clb, n, tiles, (size_t)0);
         else if (e->opt_corr_fp4)
             hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
-                               m, N, clb, n, tiles);
+                               m, N, clb, n, tiles, (size_t)0);
         else
             hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m,
                                N, clb, n, tiles);
@@ -1040,9 +1054,107 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     return CUSK_OK;
 }
 
+// forward row sums of |band|: one thread per row, float accumulation in column order (the reference's host loop,
+// corr_host.cu:112-128, so the sums are bit-identical)
+__global__ void band_row_abs_sums_kernel(const float *__restrict__ band, size_t m, size_t w, float *sums)
+{
+    const size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= m) return;
+    float acc = 0.0f;
+    for (size_t c = 0; c < w; c++) acc += fabsf(band[row * w + c]);
+    sums[row] = acc;
+}
+
+// cal_mcorrk_banded + marker_corr_banded_mat_row_abs_sums (corr_host.cu:65-128) for one chromosome
+int corr_banded_impl(cusk_engine *e, const unsigned char *bed, size_t m, size_t N, size_t width, float *rowsums_host,
+                     float *band_host)
+{
+    if (!e || !bed || !rowsums_host || m == 0 || N == 0 || width == 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t clb = (N + 3) / 4;
+    CUSK_HIP(e, e->bed_dev.ensure(m * clb));
+    DevBuf band, sums;
+    CUSK_HIP(e, band.ensure(sizeof(float) * m * width));
+    CUSK_HIP(e, sums.ensure(sizeof(float) * m));
+    CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemsetAsync(band.p, 0, sizeof(float) * m * width, s));  // pairs past the last marker stay 0
+    const int tiles = (int)((m + kMT - 1) / kMT);
+    const unsigned ndj = (unsigned)((width + kMT - 1) / kMT + 1);
+    const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 15u) == 0);
+    if (rows16)
+        hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)tiles, ndj), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
+                           band.as<float>(), m, N, clb, m, tiles, width);
+    else
+        hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)tiles, ndj), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
+                           band.as<float>(), m, N, clb, m, tiles, width);
+    hipLaunchKernelGGL(band_row_abs_sums_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, band.as<float>(), m, width,
+                       sums.as<float>());
+    CUSK_HIP(e, hipGetLastError());
+    CUSK_HIP(e, hipMemcpyAsync(rowsums_host, sums.p, sizeof(float) * m, hipMemcpyDeviceToHost, s));
+    if (band_host) CUSK_HIP(e, hipMemcpyAsync(band_host, band.p, sizeof(float) * m * width, hipMemcpyDeviceToHost, s));
+    CUSK_HIP(e, hipStreamSynchronize(s));
+    band.release();
+    sums.release();
+    return CUSK_OK;
+}
+
+// Hanning smoothing of the row-sum profile (blocking.cpp:13-35): one thread per centre, the window walked in
+// order with separate double multiply and add (this file is compiled -ffp-contract=off), so every value equals
+// the reference's host loop bit for bit; the bisection of `mps block` calls it a dozen times per chromosome and
+// the O(n * window) loop is the one host hot spot the reference has there.
+__global__ void hanning_smooth_kernel(const float *__restrict__ v, const double *__restrict__ weight, long long n, int window,
+                                      double *out)
+{
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const long long margin = window / 2;
+    double acc = 0.0;
+    if (c >= margin && c < n - margin)
+    {
+        const float *src = v + (c - margin);
+        for (int i = 0; i < window; i++) acc += weight[i] * (double)src[i];
+    }
+    out[c] = acc;
+}
+
+int hanning_smooth_impl(cusk_engine *e, const float *v_host, size_t n, const double *weight_host, int window, double *out_host)
+{
+    if (!e || !v_host || !weight_host || !out_host || n == 0 || window <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    DevBuf dv, dw, dout;
+    CUSK_HIP(e, dv.ensure(sizeof(float) * n));
+    CUSK_HIP(e, dw.ensure(sizeof(double) * (size_t)window));
+    CUSK_HIP(e, dout.ensure(sizeof(double) * n));
+    CUSK_HIP(e, hipMemcpyAsync(dv.p, v_host, sizeof(float) * n, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(dw.p, weight_host, sizeof(double) * (size_t)window, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(hanning_smooth_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, dv.as<float>(), dw.as<double>(),
+                       (long long)n, window, dout.as<double>());
+    CUSK_HIP(e, hipGetLastError());
+    CUSK_HIP(e, hipMemcpyAsync(out_host, dout.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    CUSK_HIP(e, hipStreamSynchronize(s));
+    dv.release();
+    dw.release();
+    dout.release();
+    return CUSK_OK;
+}
+
 }  // namespace cusk
 
 using namespace cusk;
+
+extern "C" int cusk_hanning_smooth(cusk_engine *e, const float *v_host, size_t n, const double *weight_host, int window,
+                                   double *out_host)
+{
+    return hanning_smooth_impl(e, v_host, n, weight_host, window, out_host);
+}
+
+extern "C" int cusk_corr_banded(cusk_engine *e, const unsigned char *bed, size_t m, size_t N, size_t width, float *rowsums_host,
+                                float *band_host)
+{
+    return corr_banded_impl(e, bed, m, N, width, rowsums_host, band_host);
+}
 
 extern "C" int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N, size_t p,
                                const float *mean, const float *std, float *C_dev, float *mxp_host)

@@ -97,6 +97,15 @@ struct BedDims
     size_t num_samples = 0, num_markers = 0;
     size_t bytes_per_col() const { return (num_samples + 3) / 4; }
 };
+// io.cpp count_lines: number of newline-terminated lines (a last line without newline counts too)
+inline size_t count_lines(const std::string &path)
+{
+    std::ifstream f(path);
+    std::string line;
+    size_t k = 0;
+    while (std::getline(f, line)) ++k;
+    return k;
+}
 inline BedDims read_dims(const std::string &path)
 {
     std::ifstream f(path);

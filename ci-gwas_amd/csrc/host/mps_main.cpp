@@ -18,6 +18,7 @@
 #include <set>
 
 #include "../../../include/cusk_hip.h"
+#include "blocking.h"
 #include "host_io.h"
 
 using namespace host;
@@ -542,10 +543,101 @@ usage: mps <command> [<args>]
 commands:
     cusk                    Run the skeleton search on a single block of block diagonal genomic covariance matrix
     cuskss                  Run the skeleton search on a block of markers and traits with pre-computed correlations.
-    prep, block             not part of the MI355X build: use the reference's CPU tools and pass their output files
+    block                   Tile the marker x marker correlation matrix of every chromosome into LD blocks
+    prep                    not part of the MI355X build: use the reference's CPU tool and pass its output files
 )";
 
 }  // namespace
+
+// ---------------------------------------------------------------------------------------
+// mps block   (cli.cpp:348-411)
+// ---------------------------------------------------------------------------------------
+const char *BLOCK_USAGE = R"(
+Tile marker x marker correlation matrix
+
+usage: mps block <bfiles> <max-block-size> <device-mem-gb> <corr-width>
+
+arguments:
+    bfiles          stem of .bed, .bim, .fam fileset
+    max-block-size  maximum number of markers per block
+    device-mem-gb   maximum memory available on gpu in GB
+    corr-width      max distance at which to compute correlations
+)";
+
+int cmd_block(int argc, char **argv)
+{
+    if (argc < 6)
+    {
+        std::cout << BLOCK_USAGE << std::endl;
+        std::exit(1);
+    }
+    const std::string bfiles = argv[2];
+    const int max_block_size = std::stoi(argv[3]);
+    const float device_mem_gb = std::stof(argv[4]);
+    const size_t corr_width = (size_t)std::stoi(argv[5]);
+    PhaseTimer tm;
+
+    std::cout << "Checking paths" << std::endl;
+    for (const char *sfx : {".bed", ".bim", ".fam"}) check_path(bfiles + sfx);
+    if (!bed_has_valid_magic(bfiles + ".bed")) die("unexpected magic number in bed file.");
+    const BimInfo bim = read_bim(bfiles + ".bim");
+    const size_t N = count_lines(bfiles + ".fam");  // BedDims(BfilesBase), io.h:41-45
+    const size_t bytes_per_marker = (N + 3) / 4;
+    const std::string out_path = bfiles + "_m" + std::to_string(max_block_size) + ".blocks";  // bfiles_base.h:35
+
+    cusk_engine *e = nullptr;
+    if (cusk_engine_create(&e, 0, nullptr) != CUSK_OK) engine_die("engine create (is a HIP device visible?)", nullptr);
+    for (const std::string &cid : bim.chr_ids)
+    {
+        const size_t m = bim.markers_on(cid);
+        const size_t mem_host_gb = (size_t)(((double)(m * bytes_per_marker) + (double)corr_width * (double)m * 4.0) * 1e-9);
+        std::cout << "[Chr " << cid << "]: At least " << mem_host_gb << " GB in host memory required." << std::endl;
+        std::cout << "[Chr " << cid << "]: Loading bed data for " << m << " markers." << std::endl;
+        Block whole;
+        whole.chr = cid;
+        whole.first = 0;
+        whole.last = m - 1;
+        BedDims dims;
+        dims.num_samples = N;
+        dims.num_markers = bim.num_lines;
+        const std::vector<unsigned char> bed = read_bed_block(bfiles + ".bed", whole, dims, bim);
+        tm.mark("read chromosome");
+
+        std::cout << "[Chr " << cid << "]: Computing correlations." << std::endl;
+        {  // corr_host.cu:73-91: the reference sizes a marker batch from the device memory it is told about
+            const double mem_bytes = (double)device_mem_gb * 1e9;
+            size_t batch = (size_t)std::floor(mem_bytes / (double)(bytes_per_marker + corr_width * 4));
+            if (batch > m) batch = m;
+            if (batch < corr_width)
+            {
+                std::printf("Maximal batch size (%zu) < corr width (%zu). Decrease distance threshold or increase device memory. \n",
+                            batch, corr_width);
+                std::exit(1);
+            }
+        }
+        std::vector<float> row_sums(m);
+        if (cusk_corr_banded(e, bed.data(), m, N, corr_width, row_sums.data(), nullptr) != CUSK_OK)
+            engine_die("banded correlations", e);
+        tm.mark("banded correlations + row sums (device)");
+        std::cout << "[Chr " << cid << "]: Computing row sums." << std::endl;
+        std::cout << "[Chr " << cid << "]: Making blocks." << std::endl;
+        const std::vector<ChrBlock> blocks =
+            blocks_of_chromosome(row_sums, max_block_size, [&](const std::vector<float> &v, const std::vector<double> &w) {
+                std::vector<double> out(v.size());
+                if (cusk_hanning_smooth(e, v.data(), v.size(), w.data(), (int)w.size(), out.data()) != CUSK_OK)
+                    engine_die("Hanning smoothing", e);
+                return out;
+            });
+        tm.mark("smoothing (device) + minima + bisection");
+        std::cout << "[Chr " << cid << "]: Partitioned into " << blocks.size() << " blocks." << std::endl;
+        std::cout << "[Chr " << cid << "]: Writing blocks to output file." << std::endl;
+        std::ofstream fout(out_path, std::ios::out | std::ios::app);  // io.cpp:266-277: appends
+        for (const ChrBlock &b : blocks) fout << cid << "\t" << b.first << "\t" << b.last << std::endl;
+    }
+    cusk_engine_destroy(e);
+    std::cout << "Done." << std::endl;
+    return 0;
+}
 
 int main(int argc, char **argv)
 {
@@ -557,7 +649,8 @@ int main(int argc, char **argv)
     const std::string cmd = argv[1];
     if (cmd == "cusk") return cmd_cusk(argc, argv);
     if (cmd == "cuskss") return cmd_cuskss(argc, argv);
-    if (cmd == "prep" || cmd == "block")
+    if (cmd == "block") return cmd_block(argc, argv);
+    if (cmd == "prep")
     {
         std::cerr << "mps " << cmd << ": outside the scope of this build (SURVEY.md 2.1); its output files are consumed as is"
                   << std::endl;

@@ -221,6 +221,15 @@ class Engine:
         self._check(lib().cusk_corr_build(self.h, _ptr(bed), _ptr(phen), m, N, p, _ptr(means), _ptr(stds), C_dev, _ptr(mxp)))
         return mxp
 
+    def corr_banded(self, bed, m: int, N: int, width: int, want_band: bool = False):
+        """`mps block`'s device part for one chromosome: forward row sums of |banded Kendall-npn correlations|
+        (and the band itself, m x width, on request)"""
+        bed = np.ascontiguousarray(bed, np.uint8)
+        sums = np.zeros(m, np.float32)
+        band = np.zeros((m, width), np.float32) if want_band else None
+        self._check(lib().cusk_corr_banded(self.h, _ptr(bed), m, N, width, _ptr(sums), _ptr(band)))
+        return (sums, band) if want_band else sums
+
     def corr_timing(self):
         t = np.zeros(4, np.float32)
         lib().cusk_corr_timing(self.h, _ptr(t))

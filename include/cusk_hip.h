@@ -166,6 +166,19 @@ int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen,
 /* timing of the last cusk_corr_build: [0] decode, [1] count GEMM, [2] mxp/pxp, [3] total (ms) */
 void cusk_corr_timing(const cusk_engine *e, float *ms4);
 
+/* `mps block` (cli.cpp:362-411): cal_mcorrk_banded + marker_corr_banded_mat_row_abs_sums, corr_host.cu:65-128.
+ * bed: packed genotypes of the m markers of ONE chromosome, SNP-major, ceil(N/4) bytes each (host).  Computes the
+ * banded Kendall-npn correlations band[row * width + col] = corr(row, row + 1 + col) (0 where row + 1 + col >= m) on
+ * the device and their forward row sums of absolute values (float accumulation in column order, as the reference's
+ * host loop).  rowsums_host: m floats out.  band_host: m * width floats out, or NULL. */
+int cusk_corr_banded(cusk_engine *e, const unsigned char *bed, size_t m, size_t N, size_t width, float *rowsums_host,
+                     float *band_host);
+/* hanning_smoothing, blocking.cpp:13-35: out[c] = sum_i weight[i] * v[c - window/2 + i] for window/2 <= c < n - window/2,
+ * 0 elsewhere; double accumulation in window order on the device (bit-identical to the host loop).  The caller supplies
+ * the window weights (0.5 - 0.5 cosf(2 pi i / (window - 1)), blocking.cpp:8-11).  All pointers are host memory. */
+int cusk_hanning_smooth(cusk_engine *e, const float *v_host, size_t n, const double *weight_host, int window,
+                        double *out_host);
+
 /* out_host[a*k + b] = M_dev[idx[a]*n + idx[b]]: the retained sub-matrix of parent_set.cpp:84-238
  * (reduce_gc / reduce_gcs) without copying the n*n matrix to the host; idx_host has k entries. */
 int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host);

@@ -995,3 +995,109 @@ void orc_corr_pearson_npn(const unsigned char *bed, const float *phen, size_t m,
     orc_marker_phen_corr_pearson(bed, phen, m, N, p, mean, std, mxp);
     orc_phen_corr_pearson(phen, N, p, pxp);
 }
+
+/* ------------------------------------------------------------------------- */
+/* mps block: banded Kendall-npn correlations, forward row sums,  */
+/* Hanning smoothing, local minima, bisection on the window size                */
+/* ------------------------------------------------------------------------- */
+
+/* cal_mcorrk_banded / cu_marker_corr_pearson_npn_batched_sparse, corr_host.cu:65-110,1199-1319 (single batch):
+ * out[row * width + col] = npn(row, row + 1 + col), 0 where row + 1 + col >= m */
+void orc_marker_corr_banded(const unsigned char *bed, size_t m, size_t N, size_t width, float *out)
+{
+    size_t clb = (N + 3) / 4;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (long long row = 0; row < (long long)m; row++) {
+        for (size_t col = 0; col < width; col++) {
+            size_t cb = (size_t)row + 1 + col;
+            float r = 0.0f;
+            if (cb < m) {
+                unsigned cnt[9] = {0};
+                for (size_t i = 0; i < clb; i++) {
+                    unsigned char ba = bed[(size_t)row * clb + i], bb = bed[cb * clb + i];
+                    for (size_t j = 0; (j < 4) && (i * 4 + j < N); j++) {
+                        float va, vb, oka, okb;
+                        bed_decode(ba, (int)j, &va, &oka);
+                        bed_decode(bb, (int)j, &vb, &okb);
+                        if (oka * okb != 0.0f) cnt[(int)(3 * va + vb)]++;
+                    }
+                }
+                float s9[9];
+                for (int i = 0; i < 9; i++) s9[i] = (float)cnt[i];
+                r = orc_npn_from_counts(s9);
+            }
+            out[(size_t)row * width + col] = r;
+        }
+    }
+}
+
+/* marker_corr_banded_mat_row_abs_sums, corr_host.cu:112-128: float accumulation, columns in order */
+void orc_banded_row_abs_sums(const float *band, size_t m, size_t width, float *sums)
+{
+    for (size_t row = 0; row < m; row++) {
+        float acc = 0.0f;
+        for (size_t col = 0; col < width; col++) acc += fabsf(band[row * width + col]);
+        sums[row] = acc;
+    }
+}
+
+/* blocking.cpp:8-11: the cosine is the single-precision one */
+static double hann(int n, int m) { return 0.5 - 0.5 * cosf(2.0 * M_PI * (double)n / ((double)m - 1.0)); }
+
+/* blocking.cpp:13-35 */
+void orc_hanning_smoothing(const float *v, int n, int window_size, double *res)
+{
+    double *win = (double *)malloc(sizeof(double) * (size_t)(window_size > 0 ? window_size : 1));
+    for (int i = 0; i < window_size; i++) win[i] = hann(i, window_size);
+    int margin = window_size / 2;
+    for (int i = 0; i < n; i++) res[i] = 0.0;
+    for (int center = margin; center < n - margin; center++)
+        for (int i = 0; i < window_size; i++) res[center] += win[i] * (double)v[center - margin + i];
+    free(win);
+}
+
+/* blocking.cpp:37-56,58-70,72-83,85-136.  first/last receive the blocks (chromosome-local marker indices);
+ * returns their number, or -1 when cap is too small */
+int orc_block_chr(const float *v, int n, int max_block_size, long long *first, long long *last, int cap)
+{
+    const int tol = 100; /* MAX_BLOCK_SIZE_TOL */
+    double *smooth = (double *)malloc(sizeof(double) * (size_t)(n > 0 ? n : 1));
+    int nb = 0, lbs = 0;
+    int too_large = n, too_small = 3;
+    int window_size = (too_large + too_small) / 2;
+    if (window_size % 2 == 0) window_size -= 1;
+    for (;;) {
+        orc_hanning_smoothing(v, n, window_size, smooth);
+        /* local minima -> blocks */
+        nb = 0;
+        lbs = 0;
+        long long prev = 0;
+        double left = 0.0;
+        int overflow = 0;
+        for (long long i = 1; i < (long long)n - 1; i++) {
+            if ((left > smooth[i]) && (smooth[i] < smooth[i + 1])) {
+                if (nb < cap) { first[nb] = prev; last[nb] = i; } else overflow = 1;
+                if ((int)(i - prev + 1) > lbs) lbs = (int)(i - prev + 1);
+                nb++;
+                prev = i + 1;
+                left = 0.0;
+            } else if (smooth[i] > left) {
+                left = smooth[i];
+            }
+        }
+        if (nb < cap) { first[nb] = prev; last[nb] = (long long)n - 1; } else overflow = 1;
+        if ((int)((long long)n - 1 - prev + 1) > lbs) lbs = (int)((long long)n - prev);
+        nb++;
+        if (overflow) { free(smooth); return -1; }
+        if (!((abs(lbs - max_block_size) > tol) || (lbs > max_block_size))) break;
+        if (lbs > max_block_size) { if (window_size < too_large) too_large = window_size; }
+        else { if (window_size > too_small) too_small = window_size; }
+        int nw = (too_large + too_small) / 2;
+        if (nw % 2 == 0) nw -= 1;
+        if (nw == window_size) break;
+        window_size = nw;
+    }
+    free(smooth);
+    return nb;
+}
+

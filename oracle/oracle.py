@@ -63,6 +63,11 @@ def lib():
         L.orc_marker_corr_npn.argtypes = [u8p, C.c_size_t, C.c_size_t, f32p]
         L.orc_npn_from_counts.restype = C.c_float
         L.orc_npn_from_counts.argtypes = [f32p]
+        L.orc_marker_corr_banded.argtypes = [u8p, C.c_size_t, C.c_size_t, C.c_size_t, f32p]
+        L.orc_banded_row_abs_sums.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p]
+        L.orc_hanning_smoothing.argtypes = [f32p, C.c_int, C.c_int, np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")]
+        L.orc_block_chr.argtypes = [f32p, C.c_int, C.c_int, i64p, i64p, C.c_int]
+        L.orc_block_chr.restype = C.c_int
         _lib = L
     return _lib
 
@@ -486,3 +491,60 @@ def load_phen(path: str):
             rows.append([np.float32(np.nan) if x == "NA" else np.float32(float(x)) for x in w[2:]])
     a = np.array(rows, np.float32)
     return a.shape[0], a.shape[1], np.ascontiguousarray(a.T).reshape(-1)
+
+
+# ---- mps block (cli.cpp:362-411, blocking.cpp, corr_host.cu:65-128) ----------------------------------
+
+def marker_corr_banded(bed, m: int, N: int, width: int) -> np.ndarray:
+    """banded Kendall-npn correlations: out[row, col] = npn(row, row + 1 + col), 0 past the last marker"""
+    bed = np.ascontiguousarray(bed, np.uint8).reshape(-1)
+    out = np.zeros((m, width), np.float32)
+    lib().orc_marker_corr_banded(bed, m, N, width, out)
+    return out
+
+
+def banded_row_abs_sums(band: np.ndarray) -> np.ndarray:
+    band = np.ascontiguousarray(band, np.float32)
+    m, w = band.shape
+    out = np.zeros(m, np.float32)
+    lib().orc_banded_row_abs_sums(band, m, w, out)
+    return out
+
+
+def hanning_smoothing(v, window_size: int) -> np.ndarray:
+    v = np.ascontiguousarray(v, np.float32)
+    out = np.zeros(len(v), np.float64)
+    lib().orc_hanning_smoothing(v, len(v), window_size, out)
+    return out
+
+
+def block_chr(v, max_block_size: int) -> list[tuple[int, int]]:
+    """(first, last) chromosome-local marker indices of the blocks"""
+    v = np.ascontiguousarray(v, np.float32)
+    cap = max(len(v), 1)
+    first = np.zeros(cap, np.int64)
+    last = np.zeros(cap, np.int64)
+    k = lib().orc_block_chr(v, len(v), max_block_size, first, last, cap)
+    assert k >= 0
+    return [(int(first[i]), int(last[i])) for i in range(k)]
+
+
+def make_blocks(bed, chr_ids, N: int, max_block_size: int, corr_width: int) -> list[str]:
+    """lines of <bfiles>_m<max_block_size>.blocks for a SNP-major bed matrix (m x ceil(N/4)) and one chromosome id per
+    marker (chromosomes in file order, cli.cpp:381-408)"""
+    bed = np.ascontiguousarray(bed, np.uint8)
+    lines = []
+    order = []
+    for c in chr_ids:
+        if c not in order:
+            order.append(c)
+    chr_ids = np.asarray(chr_ids)
+    for cid in order:
+        rows = np.nonzero(chr_ids == cid)[0]
+        sub = bed[rows[0]: rows[-1] + 1]
+        band = marker_corr_banded(sub, len(rows), N, corr_width)
+        sums = banded_row_abs_sums(band)
+        for a, b in block_chr(sums, max_block_size):
+            lines.append(f"{cid}\t{a}\t{b}")
+    return lines
+

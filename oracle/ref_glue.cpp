@@ -6,6 +6,7 @@
 // translation units (cuPC-S.cu, hetcor-cuPC-S.cu, corr_*.cu, cli.cpp) and
 // cuPC_call_prep.cpp (boost) cannot be built in this image and are not part
 // of this library.
+#include <mps/blocking.h>
 #include <mps/io.h>
 #include <mps/marker_summary_stats.h>
 #include <mps/marker_trait_summary_stats.h>
@@ -159,5 +160,27 @@ extern "C"
         std::vector<unsigned char> v = read_block_from_bed(bf.bed(), b, dims, bim);
         if (out) std::memcpy(out, v.data(), v.size());
         return (int)v.size();
+    }
+
+    // blocking.cpp:85-136 ; first/last must hold cap entries ; returns the number of blocks (or -1)
+    int ref_block_chr(const float *v, int n, int max_block_size, long long *first, long long *last, int cap)
+    {
+        std::vector<float> vv(v, v + n);
+        std::vector<MarkerBlock> b = block_chr(vv, "1", max_block_size);
+        if ((int)b.size() > cap) return -1;
+        for (size_t i = 0; i < b.size(); i++)
+        {
+            first[i] = (long long)b[i].get_first_marker_ix();
+            last[i] = (long long)b[i].get_last_marker_ix();
+        }
+        return (int)b.size();
+    }
+
+    // blocking.cpp:13-35
+    void ref_hanning_smoothing(const float *v, int n, int window_size, double *out)
+    {
+        std::vector<float> vv(v, v + n);
+        std::vector<double> r = hanning_smoothing(vv, window_size);
+        std::memcpy(out, r.data(), sizeof(double) * r.size());
     }
 }

@@ -7,6 +7,7 @@ reference checkout).  Writes DATA, never source text:
   ref_kat.json   numeric arrays parsed out of the reference's gtest fixtures
                  (cusk/include/test_data/*.h) and the expected values that the
                  reference's tests assert (cusk/tests/*_tests.cpp)
+  blocking_kat.json  the row-sum vector, smoothed prefix and expected blocks of the reference's blocking tests
   files/         byte copies of the data files under cusk/tests/test_files
                  that the cuskss / io / phen tests read
 
@@ -145,6 +146,22 @@ kat["cuskss_two_stage_block"] = dict(common, max_level_two=1, merged=False, trai
 
 with open(os.path.join(HERE, "ref_kat.json"), "w") as f:
     json.dump(kat, f, indent=1)
+
+# ---- blocking_test_set.h + blocking_tests.cpp (mps block): own file, it is 5000 numbers -----------
+t = strip_comments(read("include/test_data/blocking_test_set.h"))
+bt = strip_comments(read("tests/blocking_tests.cpp"))
+b = test_body(bt, "block_chr", "expected_results_synthetic_data")
+blocking = {
+    "test_v": array(t, "TEST_V"),                       # forward correlation row sums (float)
+    "test_v_smooth": array(t, "TEST_V_SMOOTH"),         # first 1000 entries smoothed with window 101, tolerance 0.01
+    "smooth_window": 101,
+    "smooth_tol": 0.01,
+    "chr": "1",
+    "max_block_size": 500,
+    "exp_blocks": [[int(a), int(c)] for a, c in re.findall(r'MarkerBlock\(\s*"1"\s*,\s*(\d+)\s*,\s*(\d+)\s*,\s*0\s*\)', b)],
+}
+with open(os.path.join(HERE, "blocking_kat.json"), "w") as f:
+    json.dump(blocking, f)
 
 os.makedirs(os.path.join(HERE, "files"), exist_ok=True)
 for fn in ["small_mxm.bin", "marker_indices.bin", "marker_trait_summary_stats.txt", "trait_summary_stats.txt",

@@ -16,6 +16,14 @@ def test_cusk_argv_matches_reference_order():
     assert cli.cusk_argv(a)[1:] == ["cusk", "y.phen", "stem", "b.blocks", "0.0001", "3", "14", "1", "out/", "3"]
 
 
+def test_block_argv_matches_reference_order():
+    """ci-gwas.py:390-401"""
+    from cigwas_amd import cli
+
+    args = cli.build_parser().parse_args(["block", "stem", "9000", "40", "1500"])
+    assert cli.block_argv(args) == [cli.MPS_PATH, "block", "stem", "9000", "40", "1500"]
+
+
 def test_cuskss_argv_null_sentinels_and_aliases():
     from cigwas_amd import cli
 

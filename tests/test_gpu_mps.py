@@ -150,3 +150,51 @@ def test_error_paths(tmp_path):
     assert r.returncode == 1
     r = subprocess.run([MPS, "prep", "x"], capture_output=True, text=True)
     assert r.returncode != 0
+
+
+@pytest.mark.parametrize("m,N,width", [(700, 600, 150), (333, 1001, 64), (130, 256, 129)])
+def test_banded_correlations_match_oracle(oracle, synth, m, N, width):
+    """cusk_corr_banded (the FP4 contingency kernel restricted to a band) against the oracle: band and forward row
+    sums bit-exact; widths that do and do not divide the tile, N with and without partial K blocks"""
+    import cigwas_amd as cg
+
+    bed, _phen, _means, _stds, _G = synth.synth_bed_block(m, N, 1, block_index=23, miss=0.01)
+    e = cg.Engine(0)
+    sums, band = e.corr_banded(bed, m, N, width, want_band=True)
+    e.close()
+    want = oracle.marker_corr_banded(bed, m, N, width)
+    assert np.array_equal(band, want, equal_nan=True)
+    assert np.array_equal(sums, oracle.banded_row_abs_sums(want))
+
+
+def test_mps_block_file_matches_oracle_pipeline(oracle, synth, tmp_path):
+    """`mps block` end to end on two chromosomes: the .blocks file equals the oracle's pipeline (banded npn
+    correlations -> row sums -> Hanning smoothing -> minima -> bisection), and a second run appends (io.cpp:266-277)"""
+    m1, m2, N = 1500, 900, 400
+    bed, _phen, means, stds, _G = synth.synth_bed_block(m1 + m2, N, 1, block_index=31)
+    chr_ids = ["3"] * m1 + ["7"] * m2
+    stem = str(tmp_path / "g")
+    synth.write_bfiles(stem, bed, N, means, stds, chr_ids)
+    txt = _run(["block", stem, "300", "1", "200"])
+    assert "[Chr 3]: Partitioned into" in txt and "[Chr 7]: Partitioned into" in txt
+    want = oracle.make_blocks(bed, chr_ids, N, 300, 200)
+    path = stem + "_m300.blocks"
+    got = open(path).read().splitlines()
+    assert got == want and len(want) > 4
+    # every chromosome is covered exactly once, in order
+    for cid, mm in (("3", m1), ("7", m2)):
+        rows = [tuple(map(int, l.split("\t")[1:])) for l in got if l.split("\t")[0] == cid]
+        assert rows[0][0] == 0 and rows[-1][1] == mm - 1 and all(rows[i + 1][0] == rows[i][1] + 1 for i in range(len(rows) - 1))
+    _run(["block", stem, "300", "1", "200"])
+    assert open(path).read().splitlines() == want + want
+    # the block file drives `mps cusk` unchanged
+    assert oracle.read_blocks(path)[: len(want)] is not None
+
+
+def test_mps_block_refuses_band_wider_than_the_chromosome(synth, tmp_path):
+    bed, _phen, means, stds, _G = synth.synth_bed_block(100, 200, 1, block_index=2)
+    stem = str(tmp_path / "g")
+    synth.write_bfiles(stem, bed, 200, means, stds)
+    r = subprocess.run([MPS, "block", stem, "50", "1", "500"], capture_output=True, text=True)
+    assert r.returncode == 1 and "corr width" in r.stdout
+

@@ -145,3 +145,16 @@ def test_ci_test_matches_float64_partial_correlation(oracle, synth):
             want = -P[0, 1] / np.sqrt(P[0, 0] * P[1, 1])
             assert abs(rho - want) < 1e-5
             assert abs(z - abs(np.arctanh(want))) < 1e-5
+
+
+def test_blocking_kat(oracle, golden_dir):
+    """blocking_tests.cpp: block_chr(TEST_V, "1", 500) -> 17 exact blocks; hanning_smoothing of the first 1000 entries"""
+    import json
+    import os
+
+    k = json.load(open(os.path.join(golden_dir, "..", "blocking_kat.json")))
+    v = np.array(k["test_v"], np.float32)
+    assert oracle.block_chr(v, k["max_block_size"]) == [tuple(b) for b in k["exp_blocks"]]
+    sm = oracle.hanning_smoothing(v[:1000], k["smooth_window"])
+    assert np.allclose(sm, np.array(k["test_v_smooth"]), rtol=0, atol=k["smooth_tol"])
+

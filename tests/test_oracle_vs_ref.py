@@ -168,3 +168,28 @@ def test_het_loaders_with_se(oracle, ref, tmp_path):
                           _p(corr), _p(ess), C.byref(nph))
     c2, e2 = oracle.load_mxp(str(tmp_path / "mxp.txt"), range(1, 5), se_path=str(tmp_path / "mxp_se.txt"))
     assert nm == 4 and np.array_equal(corr.reshape(4, p), c2) and np.array_equal(ess.reshape(4, p), e2, equal_nan=True)
+
+
+@pytest.mark.parametrize("seed,n,maxb", [(0, 3000, 300), (1, 5000, 800), (2, 1200, 150), (3, 800, 2000)])
+def test_blocking_matches_reference_code(oracle, ref, seed, n, maxb):
+    """the oracle's restatement of blocking.cpp against the reference's own blocking.cpp (compiled in place):
+    smoothed curve bit-equal, identical blocks, on random LD-like row-sum profiles"""
+    rng = np.random.default_rng(100 + seed)
+    # forward |r| row sums look like a noisy positive curve with dips at block boundaries
+    base = 20.0 + 10.0 * np.sin(np.arange(n) / 37.0) + 5.0 * np.sin(np.arange(n) / 211.0 + seed)
+    dips = np.ones(n)
+    for c in rng.integers(50, n - 50, size=max(3, n // 250)):
+        dips[max(0, c - 15): c + 15] *= rng.uniform(0.2, 0.6)
+    v = (base * dips + rng.normal(0.0, 0.8, n)).astype(np.float32)
+    ref.ref_hanning_smoothing.restype = None
+    for ws in (5, 101, 333):
+        r = np.zeros(n, np.float64)
+        ref.ref_hanning_smoothing(_p(v), C.c_int(n), C.c_int(ws), _p(r))
+        assert np.array_equal(oracle.hanning_smoothing(v, ws), r)
+    first = np.zeros(n, np.int64)
+    last = np.zeros(n, np.int64)
+    ref.ref_block_chr.restype = C.c_int
+    k = ref.ref_block_chr(_p(v), C.c_int(n), C.c_int(maxb), _p(first), _p(last), C.c_int(n))
+    assert k > 0
+    assert oracle.block_chr(v, maxb) == [(int(first[i]), int(last[i])) for i in range(k)]
+
