@@ -32,10 +32,18 @@ def per_launch(kpat):
     w = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "WRITE_SIZE"]
     return (f[0] if f else 0.0) * 1024, (w[0] if w else 0.0) * 1024
 f1, w1 = per_launch("level1_rows_kernel")
-json.dump({"level1": f1 + w1, "level1_fetch": f1, "level1_write": w1,
-           "note": "HBM-side bytes per launch of level1_rows_kernel<0,false> = (FETCH_SIZE + WRITE_SIZE) x 1024 from separate PMC "
-                   "passes (" + TAG + "); FETCH_SIZE taken as reported: the kernel's reads are 4-byte-per-lane streams and gathers, "
-                   "not the 16-byte-per-lane streams the gfx950 2x correction applies to"},
+# calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"): the level-0 kernel
+# streams the upper triangle of the 10020^2 fp32 matrix once with the same 4-byte-per-lane coalesced loads
+f0, _ = per_launch("level0_wide_kernel")
+n0 = 10020
+known0 = 4.0 * n0 * (n0 - 1) / 2
+cal = known0 / f0 if f0 > 0 else 1.0
+json.dump({"level1": f1 * cal + w1, "level1_fetch_reported": f1, "level1_write": w1, "fetch_calibration": cal,
+           "level0_fetch_reported": f0, "level0_known_bytes": known0,
+           "note": "HBM-side bytes per launch of level1_rows_kernel<0,false>: FETCH_SIZE x 1024 x calibration + WRITE_SIZE x 1024, "
+                   "separate PMC passes (" + TAG + "). Calibration: level0_wide_kernel reads a known " + str(int(known0)) +
+                   " bytes (upper triangle, 4-byte-per-lane coalesced loads, the same access width as the level-1 streams) and "
+                   "FETCH_SIZE reports 1/calibration of them (gfx950 tallies 128-byte requests at 64 bytes)"},
           open(f"{O}/pmc_traffic.json", "w"), indent=1)
 PY
 ls $O | head -30
