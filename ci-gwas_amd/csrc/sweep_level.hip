@@ -950,18 +950,18 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
             }
             else
             {
+                // hetcor: the edge goes in both directions; both directed slots are marked with plain stores (racing
+                // writers store the same 0) and the bitmap / degrees are updated once afterwards (level1_apply_kernel),
+                // so the sweep carries no returning atomics
                 if (passB)
                 {
-                    // edge X - yb goes: mark both directed slots, clear both bits
                     rp.sel[cur.ib] = 0u;
                     rp.sel[p.off[yb] + rp.meta[cur.ib].y] = 0u;
-                    if (clear_edge(p.adj, p.deg, p.words, cur.X, yb)) nrem++;
                 }
                 if (headA)
                 {
                     rp.sel[cur.ia] = 0u;
                     rp.sel[o0 + rp.meta[cur.ia].y] = 0u;
-                    if (clear_edge(p.adj, p.deg, p.words, cur.X, ya)) nrem++;
                 }
             }
         };
@@ -1047,6 +1047,51 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
     }
 }
 
+// hetcor mode, after the sweep: every row drops the neighbours whose slot was marked (the wave owns its bitmap row:
+// word-aggregated plain read-modify-writes as in gather_records), sets its degree, and the removed directed edges
+// are counted
+__global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict__ off, const int *__restrict__ nbr,
+                                                           const unsigned *__restrict__ sel, unsigned long long *adj, int *deg,
+                                                           int n, int words, unsigned long long *slots)
+{
+    __shared__ int s_sum[4];
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    int removed = 0;
+    if (row < n)
+    {
+        const int o0 = off[row], d = off[row + 1] - o0;
+        for (int k0 = 0; k0 < d; k0 += 64)
+        {
+            const int k = k0 + lane;
+            const bool valid = k < d;
+            const int Y = valid ? nbr[o0 + k] : 0;
+            const bool gone = valid && (sel[o0 + k] == 0u);
+            const int w = valid ? (Y >> 6) : -1 - lane;
+            unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1)
+            {
+                const unsigned long long ob = __shfl_down(bits, o);
+                const int ow = __shfl_down(w, o);
+                if (lane + o < 64 && ow == w) bits |= ob;
+            }
+            const int pw = __shfl_up(w, 1);
+            if (valid && bits != 0ull && (lane == 0 || pw != w)) adj[(size_t)row * words + w] &= ~bits;
+            removed += __popcll(__ballot(gone));
+        }
+        if (lane == 0 && removed) deg[row] = d - removed;
+    }
+    if (lane == 0) s_sum[threadIdx.x >> 6] = removed;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+        // cusk_stats.removed: ordered pairs, as in Skeleton mode (both directions of an edge go)
+        if (t) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+    }
+}
+
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t st)
 {
@@ -1073,6 +1118,9 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (mode == 0)
         hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
                            p.slots);
+    else
+        hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
+                           p.words, p.slots);
     return hipGetLastError();
 }
 
