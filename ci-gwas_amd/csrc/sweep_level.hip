@@ -108,8 +108,27 @@ __global__ void __launch_bounds__(256) level0_kernel(const float *__restrict__ C
             }
             if constexpr (ESS)
             {
-                const float lth = (float)((double)th / sqrt((double)nv[rr] - 3.0));
-                rm = z_below<false>(c, lth);
+                // per-pair threshold th / sqrt(N_ij - 3): a single-precision estimate of z sqrt(N_ij - 3) settles the
+                // element unless it falls within 1e-3 of th (or the threshold is too small for that band, or an
+                // operand is unusual); only then the reference's double-precision threshold and Fisher z are formed
+                const float nm3 = nv[rr] - 3.0f;
+                const float ac = fabsf(c);
+                int fastv = 2;
+                if (nm3 > 0.0f && nm3 < 3.0e38f && ac < 1.0f && th * __frsqrt_rn(nm3) >= kThMinFilter)
+                {
+                    const float sest = 0.5f * fabsf(__logf((1.0f + ac) / (1.0f - ac))) * __fsqrt_rn(nm3);
+                    if (sest < th * (1.0f - 1e-3f))
+                        fastv = 1;
+                    else if (sest > th * (1.0f + 1e-3f))
+                        fastv = 0;
+                }
+                if (fastv == 2)
+                {
+                    const float lth = (float)((double)th / sqrt((double)nv[rr] - 3.0));
+                    rm = z_below<false>(c, lth);
+                }
+                else
+                    rm = (fastv == 1);
             }
             else
             {
