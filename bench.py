@@ -52,6 +52,8 @@ def main():
                     help="cusk: Skeleton engine (sepsets + pMax); cuskss: hetcor engine with uniform ESS")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
+                    help="engine option for kernel experiments (cusk_set_option); the default run sets none")
     ap.add_argument("--cpu-sample-markers", type=int, default=10000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(16, affinity))")
     args = ap.parse_args()
@@ -90,6 +92,9 @@ def main():
     eng = cg.Engine(local_rank)
     # the matrix is written by cusk_corr_build, which mirrors every element: symmetric by construction
     eng.set_option("assume_symmetric", 1)
+    for kv in args.option:
+        k, v = kv.split("=")
+        eng.set_option(k, int(v))
     Cd = cg.DeviceArray(nbytes=4 * n * n)
     eng.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr)  # warm
     eng.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr)

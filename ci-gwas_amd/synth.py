@@ -248,3 +248,59 @@ def hub_corr(nleaf: int, nhub: int, seed: int, noise: float = 1.0) -> np.ndarray
     C = np.minimum(C, C.T)
     np.fill_diagonal(C, 1.0)
     return np.ascontiguousarray(C)
+
+
+def merged_skeleton(seed: int, p: int, m: int, duplicates: int = 0, with_prior: bool = False, block: int = 5,
+                    trait_edge_prob: float = 0.35):
+    """A merged cusk skeleton in the layout `merge-block-outputs` writes (traits 0..p-1, then m selected markers):
+    the population correlation matrix of a linear model -- markers in LD blocks of `block`, each trait driven by
+    a few markers, a random lower-triangular trait DAG -- and an adjacency read off it.  Marker-marker entries
+    outside a block are dropped (zero), as in a merged `_scm.mtx`; the trait rows and columns are complete, so
+    every sub-matrix the separation-set search inverts is positive definite.  `duplicates` markers are exact
+    copies of their predecessor (what `rm_collinear_markers` is there for).
+    Returns (adj bool n x n, corr f64 n x n with unit diagonal, ixs i32 m, prior i32 p x p or None)."""
+    rng = np.random.default_rng(seed)
+    n = p + m
+    blk = np.arange(m) // block
+    Sm = np.where(blk[:, None] == blk[None, :], 0.6 ** np.abs(np.arange(m)[:, None] - np.arange(m)[None, :]), 0.0)
+    B = np.zeros((p, m))
+    for t in range(p):
+        k = rng.integers(2, 5)
+        cols = rng.choice(m, size=min(k, m), replace=False)
+        B[t, cols] = rng.uniform(0.12, 0.35, size=cols.size) * rng.choice([-1.0, 1.0], size=cols.size)
+    A = np.tril(rng.uniform(0.15, 0.45, size=(p, p)) * rng.choice([-1.0, 1.0], size=(p, p)), -1)
+    A *= np.tril(rng.random((p, p)) < trait_edge_prob, -1)
+    T = np.linalg.inv(np.eye(p) - A)
+    # variables [traits, markers]:  y = T (B x + e),  x ~ (0, Sm),  e ~ (0, I)
+    cov = np.zeros((n, n))
+    cov[p:, p:] = Sm
+    cov[:p, p:] = T @ B @ Sm
+    cov[p:, :p] = cov[:p, p:].T
+    cov[:p, :p] = T @ (B @ Sm @ B.T + np.eye(p)) @ T.T
+    sd = np.sqrt(np.diag(cov))
+    corr = cov / np.outer(sd, sd)
+    corr = 0.5 * (corr + corr.T)
+    dup = rng.choice(np.arange(1, m), size=duplicates, replace=False) if duplicates else []
+    for b in dup:  # marker b becomes an exact copy of marker b - 1
+        a = p + b - 1
+        b = p + b
+        corr[b, :] = corr[a, :]
+        corr[:, b] = corr[:, a]
+        corr[a, b] = corr[b, a] = 1.0
+    np.fill_diagonal(corr, 1.0)
+    same_block = np.zeros((n, n), dtype=bool)
+    same_block[p:, p:] = blk[:, None] == blk[None, :]
+    adj = np.abs(corr) > 0.08
+    adj[p:, p:] &= same_block[p:, p:] & (np.abs(corr[p:, p:]) > 0.2)
+    np.fill_diagonal(adj, False)
+    keep = np.ones((n, n), dtype=bool)
+    keep[p:, p:] = same_block[p:, p:]
+    corr = np.where(keep, corr, 0.0)
+    ixs = np.sort(rng.choice(50 * m, size=m, replace=False)).astype(np.int32)
+    prior = None
+    if with_prior:
+        prior = np.zeros((p, p), dtype=np.int32)
+        ii, jj = np.nonzero(np.triu(adj[:p, :p], 1))
+        for k in rng.choice(ii.size, size=min(3, ii.size), replace=False) if ii.size else []:
+            prior[jj[k], ii[k]] = 1
+    return adj, corr, ixs, prior
