@@ -57,6 +57,7 @@ SYMBOLS = {
     "cusk_corr_timing": (None, [_vp, _vp]),
     "cusk_corr_banded": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "cusk_hanning_smooth": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
+    "cusk_sepselect_greedy": (_i, [_vp, _vp, C.c_longlong, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cusk_gather_submatrix": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "cusk_dev_alloc": (_vp, [_sz]),
     "cusk_dev_free": (None, [_vp]),

@@ -8,7 +8,9 @@ the native `mps` program with literal 'NULL' for absent paths, `subprocess.run(c
 `cuskss-het` and `cuskss-merged` (README.md:65,75 of the reference names them, its CLI does
 not define them) are aliases of `cuskss` that insist on the flags that select that mode.
 
-Everything downstream (merge-block-outputs, sepselect, srfci, mvivw) is the reference's own
+`sepselect` and `orient-v-structs` (ci-gwas.py:303-358, handlers :467-476) run this package's device-backed
+mirror of cusk_postprocessing/sepselect.py (ci-gwas_amd/sepselect.py) and write the same files.
+The rest of the downstream (merge-block-outputs, srfci, mvivw) is the reference's own
 code and consumes the files written here unchanged; after a merged run the reference's
 `reformat_cuskss_merged_output` is invoked when its package is importable.
 """
@@ -92,6 +94,25 @@ def _add_cuskss(sub, name, help_):
     p.set_defaults(func=cuskss, variant=name)
 
 
+def _add_sepselect(sub):
+    """ci-gwas.py:303-358"""
+    for name, help_, func in (
+            ("orient-v-structs", "Orient v-structures using maximal separation sets on merged cusk skeletons.", run_v_struct),
+            ("sepselect", "Compute maximal and partial-correlation-minimizing separation sets on merged cusk skeletons",
+             run_sepselect)):
+        p = sub.add_parser(name, help=help_)
+        p.add_argument("cusk_result_stem", metavar="cusk-result-stem", type=str, help="outdir + stem of merged cusk results")
+        p.add_argument("alpha", type=TypeCheck(float, "alpha", 0.0, 1.0), default=10**-4,
+                       help="significance level for conditional independence tests")
+        p.add_argument("num_samples", metavar="num-samples", type=TypeCheck(int, "num-samples", 1, None),
+                       help="number of samples used for computing correlations")
+        if name == "orient-v-structs":
+            p.add_argument("--orientation-prior", metavar="orientation-prior", type=str, default=None,
+                           help="matrix of (0, 1) (32 bit integers, binary) of dims (n_trait, n_trait) indicating "
+                                "directions to be forced. ")
+        p.set_defaults(func=func)
+
+
 def build_parser() -> argparse.ArgumentParser:
     parser = _Parser(prog="ci-gwas", description="cusk / cuskss steps of CI-GWAS on AMD Instinct MI355X")
     sub = parser.add_subparsers(required=True, title="subcommands")
@@ -100,6 +121,7 @@ def build_parser() -> argparse.ArgumentParser:
     _add_cuskss(sub, "cuskss", "Infer skeleton using summary statistic data (requires GPU)")
     _add_cuskss(sub, "cuskss-het", "cuskss with heterogeneous (polychoric/polyserial) correlations: needs --mxp-se/--pxp-se")
     _add_cuskss(sub, "cuskss-merged", "cuskss on the union of markers selected in all blocks: needs --marker-indices")
+    _add_sepselect(sub)
     return parser
 
 
@@ -151,6 +173,24 @@ def cuskss(args):
                              "reformat_cuskss_merged_output on the output directory\n")
             return
         reformat_cuskss_merged_output(cusk_dir=args.outdir).write_mm(basepath=f"{args.outdir}/cuskss_merged")
+
+
+def run_sepselect(args):
+    """ci-gwas.py:467-470"""
+    from .sepselect import sepselect_merged
+
+    merged_cusk = sepselect_merged(args.cusk_result_stem, args.alpha, args.num_samples)
+    merged_cusk.to_file(f"{os.path.dirname(args.cusk_result_stem)}/max_sep_min_pc")
+    print("Sepselect done.")
+
+
+def run_v_struct(args):
+    """ci-gwas.py:473-476"""
+    from .sepselect import orient_v_structures_merged
+
+    merged_cusk = orient_v_structures_merged(args.cusk_result_stem, args.alpha, args.num_samples, args.orientation_prior)
+    merged_cusk.to_file(f"{os.path.dirname(args.cusk_result_stem)}/max_sep_min_pc")
+    print("Sepselect / v-structs done.")
 
 
 def main(argv=None):

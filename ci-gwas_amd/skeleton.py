@@ -230,6 +230,29 @@ class Engine:
         self._check(lib().cusk_corr_banded(self.h, _ptr(bed), m, N, width, _ptr(sums), _ptr(band)))
         return (sums, band) if want_band else sums
 
+    def sepselect_greedy(self, trait_corr, pair_i, pair_j, pair_corr, cand_off, cand, thr):
+        """Batched greedy separating-set selection (sepselect.py:262-329) on the device.  Returns
+        (sel, sel_len, flags, kernel_ms); see include/cusk_hip.h for the layouts."""
+        trait_corr = np.ascontiguousarray(trait_corr, np.float64)
+        n, p = trait_corr.shape
+        pair_i = np.ascontiguousarray(pair_i, np.int32)
+        pair_j = np.ascontiguousarray(pair_j, np.int32)
+        pair_corr = np.ascontiguousarray(pair_corr, np.float64)
+        cand_off = np.ascontiguousarray(cand_off, np.int64)
+        cand = np.ascontiguousarray(cand, np.int32)
+        thr = np.ascontiguousarray(thr, np.float64)
+        npairs = pair_i.shape[0]
+        assert pair_j.shape[0] == npairs and pair_corr.shape[0] == npairs and cand_off.shape[0] == npairs + 1
+        assert cand.shape[0] == int(cand_off[-1])
+        sel = np.full(max(cand.shape[0], 1), -1, np.int32)
+        sel_len = np.zeros(max(npairs, 1), np.int32)
+        flags = np.zeros(max(npairs, 1), np.int32)
+        ms = np.zeros(1, np.float32)
+        self._check(lib().cusk_sepselect_greedy(self.h, _ptr(trait_corr), n, p, npairs, _ptr(pair_i), _ptr(pair_j),
+                                                _ptr(pair_corr), _ptr(cand_off), _ptr(cand), _ptr(thr), thr.shape[0],
+                                                _ptr(sel), _ptr(sel_len), _ptr(flags), _ptr(ms)))
+        return sel, sel_len[:npairs], flags[:npairs], float(ms[0])
+
     def corr_timing(self):
         t = np.zeros(4, np.float32)
         lib().cusk_corr_timing(self.h, _ptr(t))

@@ -251,13 +251,15 @@ def hub_corr(nleaf: int, nhub: int, seed: int, noise: float = 1.0) -> np.ndarray
 
 
 def merged_skeleton(seed: int, p: int, m: int, duplicates: int = 0, with_prior: bool = False, block: int = 5,
-                    trait_edge_prob: float = 0.35):
+                    trait_edge_prob: float = 0.35, noise: float = 0.0):
     """A merged cusk skeleton in the layout `merge-block-outputs` writes (traits 0..p-1, then m selected markers):
     the population correlation matrix of a linear model -- markers in LD blocks of `block`, each trait driven by
     a few markers, a random lower-triangular trait DAG -- and an adjacency read off it.  Marker-marker entries
     outside a block are dropped (zero), as in a merged `_scm.mtx`; the trait rows and columns are complete, so
     every sub-matrix the separation-set search inverts is positive definite.  `duplicates` markers are exact
-    copies of their predecessor (what `rm_collinear_markers` is there for).
+    copies of their predecessor (what `rm_collinear_markers` is there for).  `noise` > 0 adds symmetric Gaussian
+    estimation noise of that scale to the stored off-diagonal entries (population values carry structural exact
+    zeros and with them exact ties between candidates, which sample correlations do not have).
     Returns (adj bool n x n, corr f64 n x n with unit diagonal, ixs i32 m, prior i32 p x p or None)."""
     rng = np.random.default_rng(seed)
     n = p + m
@@ -296,6 +298,14 @@ def merged_skeleton(seed: int, p: int, m: int, duplicates: int = 0, with_prior: 
     keep = np.ones((n, n), dtype=bool)
     keep[p:, p:] = same_block[p:, p:]
     corr = np.where(keep, corr, 0.0)
+    if noise > 0.0:
+        g = np.random.default_rng(seed + 7919).normal(scale=noise, size=(n, p))
+        e = np.zeros((n, n))
+        e[:, :p] = g
+        e[:p, :] = g.T
+        e[:p, :p] = 0.5 * (g[:p] + g[:p].T)
+        np.fill_diagonal(e, 0.0)
+        corr = corr + e
     ixs = np.sort(rng.choice(50 * m, size=m, replace=False)).astype(np.int32)
     prior = None
     if with_prior:

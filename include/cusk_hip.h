@@ -179,6 +179,27 @@ int cusk_corr_banded(cusk_engine *e, const unsigned char *bed, size_t m, size_t 
 int cusk_hanning_smooth(cusk_engine *e, const float *v_host, size_t n, const double *weight_host, int window,
                         double *out_host);
 
+/* `sepselect` / `orient-v-structs` hot loop: cusk_postprocessing/sepselect.py:262-329
+ * (MergedCuskResults.find_maximal_and_min_pcorr_sepsets_incr) for a batch of outer pairs, one wavefront per pair.
+ * All pointers are HOST memory.
+ *   trait_corr  n x p doubles, row-major: corr[v, t] of every variable v with every trait t (merged layout: the
+ *               traits are variables 0 .. p-1); the matrix must be symmetric on these entries
+ *   pair_i/j    the outer pairs (variable indices), pair_corr[k] = corr[pair_i[k], pair_j[k]]
+ *   cand_off    npairs + 1 offsets into cand; cand = the trait neighbours of pair_i[k] in the order the
+ *               reference's loop visits them (iteration order of its Python set); ties of the minimum go to the
+ *               LAST candidate in that order, as `<=` does at sepselect.py:286
+ *   thr         thr[l] = norm.ppf(1 - alpha/2) / sqrt(num_samples - l - 3) (sepselect.py:25-26), l = 0 .. nthr-1,
+ *               nthr > longest candidate list
+ * Out: sel (cand_off layout) = the accepted traits of pair k in order, sel_len[k] of them (the maximal separating
+ * set, :311); flags[k] bit 0 = the round-wise minimum of the partial correlation was passed (:292-294: the pair
+ * gets an entry in min_pcorr_sepsets), flags[k] >> 8 = 0 ok, 1 = no candidate had a comparable z (the reference
+ * fails on remove(None) there), 2 = a sub-matrix was exactly singular (the reference exits, :12-18).
+ * kernel_ms (may be NULL): device time of the selection kernels alone. */
+int cusk_sepselect_greedy(cusk_engine *e, const double *trait_corr, long long n, int p, long long npairs,
+                          const int *pair_i, const int *pair_j, const double *pair_corr, const long long *cand_off,
+                          const int *cand, const double *thr, int nthr, int *sel, int *sel_len, int *flags,
+                          float *kernel_ms);
+
 /* out_host[a*k + b] = M_dev[idx[a]*n + idx[b]]: the retained sub-matrix of parent_set.cpp:84-238
  * (reduce_gc / reduce_gcs) without copying the n*n matrix to the host; idx_host has k entries. */
 int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host);

@@ -108,34 +108,40 @@ def partial_z(corr, variables):
     return fisher_z(-(prec[0, 1] / np.sqrt(np.abs(prec[0, 0] * prec[1, 1]))))
 
 
+def greedy_pair(corr, i, j, pool, alpha, num_samples):
+    """:267-311 for one outer pair; `pool` is consumed.  Returns (chosen list, minimum seen?)"""
+    chosen = []
+    separated = partial_z(corr, [i, j]) < z_threshold(alpha, num_samples, 0)
+    seen_minimum = False
+    previous = np.inf
+    for size in range(1, len(pool) + 1):
+        best, pick = np.inf, None
+        for t in pool:
+            z = partial_z(corr, [i, j] + chosen + [t])
+            if z <= best:
+                best, pick = z, t
+        if best > previous and separated and not seen_minimum:
+            seen_minimum = True  # from here on the reference's "minimum" entry is this same, still growing, list
+        indep = best < z_threshold(alpha, num_samples, size)
+        if separated and not indep:
+            break
+        separated = separated or indep
+        previous = best
+        chosen.append(pick)
+        pool.remove(pick)
+    return chosen, seen_minimum
+
+
 def greedy_sepsets(g, pairs, alpha, num_samples):
     """:262-329 -- returns {pair: list} of maximal sets and {pair: list} of the pairs that saw a minimum"""
     corr, adj, num_phen = g["corr"], g["adj"], g["num_phen"]
     grown, with_minimum = {}, {}
     for (i, j) in pairs:
         row = np.flatnonzero(adj[i])
-        pool = set(row[row < num_phen])
-        chosen = []
-        separated = partial_z(corr, [i, j]) < z_threshold(alpha, num_samples, 0)
-        seen_minimum = False
-        previous = np.inf
-        for size in range(1, len(pool) + 1):
-            best, pick = np.inf, None
-            for t in pool:
-                z = partial_z(corr, [i, j] + chosen + [t])
-                if z <= best:
-                    best, pick = z, t
-            if best > previous and separated and not seen_minimum:
-                seen_minimum = True
-                with_minimum[(i, j)] = chosen  # the same list object: it keeps growing below
-            indep = best < z_threshold(alpha, num_samples, size)
-            if separated and not indep:
-                break
-            separated = separated or indep
-            previous = best
-            chosen.append(pick)
-            pool.remove(pick)
+        chosen, seen = greedy_pair(corr, i, j, set(row[row < num_phen]), alpha, num_samples)
         grown[(i, j)] = chosen
+        if seen:
+            with_minimum[(i, j)] = chosen
     return grown, with_minimum
 
 

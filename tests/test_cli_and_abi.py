@@ -98,3 +98,17 @@ def test_thresholds_match_oracle(oracle):
     for n, a in [(10000, 1e-5), (16384, 1e-4), (458747, 1e-4), (500, 0.05), (50, 1e-2), (500000, 1e-8)]:
         assert np.array_equal(cg.threshold_array(n, a), oracle.threshold_array(n, a))
         assert cg.hetcor_threshold(a) == oracle.hetcor_threshold(a)
+
+
+def test_sepselect_subcommands_match_reference_arguments():
+    """ci-gwas.py:303-358: positional stem, alpha, num-samples; --orientation-prior only on orient-v-structs"""
+    from cigwas_amd import cli
+
+    p = cli.build_parser()
+    a = p.parse_args(["orient-v-structs", "out/all_merged", "0.0001", "458747", "--orientation-prior", "prior.bin"])
+    assert (a.cusk_result_stem, a.alpha, a.num_samples, a.orientation_prior) == ("out/all_merged", 1e-4, 458747, "prior.bin")
+    assert a.func is cli.run_v_struct
+    a = p.parse_args(["sepselect", "out/all_merged", "0.001", "1000"])
+    assert a.func is cli.run_sepselect and not hasattr(a, "orientation_prior")
+    with pytest.raises(SystemExit):
+        p.parse_args(["sepselect", "out/all_merged", "1.5", "1000"])  # alpha outside (0, 1)

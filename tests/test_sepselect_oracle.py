@@ -50,3 +50,23 @@ def test_oracle_reproduces_reference_files(name, tmp_path):
     ostem = os.path.join(str(tmp_path), "max_sep_min_pc")
     SO.write(res, ostem)
     check_outputs(case, ostem)
+
+
+@pytest.mark.parametrize("name", ["small", "collinear", "wide"])
+def test_host_graph_logic_matches_reference_files(name, tmp_path):
+    """the product's host side up to (not including) the device launch: loader, collinear-marker removal,
+    unshielded triples in the reference's row order"""
+    from cigwas_amd import sepselect as SS
+
+    case = load_cases()[name]
+    stem, prior = materialise(case, str(tmp_path))
+    cr = SS.MergedCuskResults(stem, orientation_prior_file=prior)
+    exp = case["output"]
+    assert cr.get_rfci_relevant_unshielded_triples().ravel().tolist() == exp["ut"]
+    assert cr.num_var == int(exp["mdim"].split()[0])
+    from oracle import sepselect_oracle as SO
+
+    g = SO.load_merged(stem)
+    assert np.array_equal(g["adj"], cr.adj) and np.array_equal(g["corr"], cr.corr) and np.array_equal(g["ixs"], cr.ixs)
+    assert SO.unshielded_triples(g["adj"]) == cr.get_unshielded_triples()
+    assert list(SO.unshielded_triples(g["adj"])) == list(cr.get_unshielded_triples())  # same iteration order
