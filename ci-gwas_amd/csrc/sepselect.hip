@@ -44,6 +44,13 @@ struct SepBatch
     long long ws_stride;    // doubles per pair in ws
 };
 
+// e = a * w + c with 0 <= c < w: float reciprocal while it is exact (w <= 512, e < 2^18), integer division beyond
+__device__ __forceinline__ void split_index(int e, int w, float inv_w, int &a, int &c)
+{
+    a = (w <= 512) ? (int)(((float)e + 0.5f) * inv_w) : e / w;
+    c = e - a * w;
+}
+
 __device__ __forceinline__ double abs_fisher_z(double r) { return fabs(0.5 * log(fabs((1.0 + r) / (1.0 - r)))); }
 
 template <bool IN_LDS>
@@ -55,13 +62,13 @@ __global__ void __launch_bounds__(64) sepselect_kernel(SepBatch b, int cap)
     const long long c0 = b.cand_off[pid];
     const int t = (int)(b.cand_off[pid + 1] - c0);
     const int ld = cap | 1;
-    // carve: M[cap * ld], ui[cap], uj[cap], col[cap], fcl[cap], alive[cap] (ints)
+    // carve: M[cap * ld], ui[cap], uj[cap], col[cap], fcl[cap], rem[cap] (ints)
     double *M = IN_LDS ? s_mem : b.ws + (size_t)blockIdx.x * b.ws_stride;
     double *ui = M + (size_t)cap * ld;
     double *uj = ui + cap;
     double *col = uj + cap;
     double *fcl = col + cap;
-    int *alive = reinterpret_cast<int *>(fcl + cap);
+    int *rem = reinterpret_cast<int *>(fcl + cap);  // remaining candidates, iteration order kept
     const int vi = b.pair_i[pid], vj = b.pair_j[pid];
     const int p = b.p;
     for (int k = lane; k < t; k += 64)
@@ -69,12 +76,16 @@ __global__ void __launch_bounds__(64) sepselect_kernel(SepBatch b, int cap)
         const int tk = b.cand[c0 + k];
         ui[k] = b.tc[(size_t)vi * p + tk];
         uj[k] = b.tc[(size_t)vj * p + tk];
-        alive[k] = 1;
+        rem[k] = k;
     }
-    for (int e = lane; e < t * t; e += 64)
     {
-        const int a = e / t, c = e - a * t;
-        M[a * ld + c] = b.tc[(size_t)b.cand[c0 + a] * p + b.cand[c0 + c]];
+        const float inv_t = 1.0f / (float)max(t, 1);
+        for (int e = lane; e < t * t; e += 64)
+        {
+            int a, c;
+            split_index(e, t, inv_t, a, c);
+            M[a * ld + c] = b.tc[(size_t)b.cand[c0 + a] * p + b.cand[c0 + c]];
+        }
     }
     __syncthreads();
     double rii = 1.0, rjj = 1.0, rij = b.pair_c[pid];
@@ -84,15 +95,16 @@ __global__ void __launch_bounds__(64) sepselect_kernel(SepBatch b, int cap)
     bool seen_minimum = false;
     double previous = INFINITY;
     int len = 0;
-    for (int size = 1; size <= t && status == 0; size++)
+    for (int r = t; r > 0 && status == 0; r--)
     {
+        const int size = t - r + 1;
         // ---- every remaining candidate through its 3 x 3 Schur complement ----
         double best = INFINITY;
-        int pick = -1;
+        int pick = -1;  // position in rem[]
         bool singular = false;
-        for (int k = lane; k < t; k += 64)
+        for (int q = lane; q < r; q += 64)
         {
-            if (!alive[k]) continue;
+            const int k = rem[q];
             const double mkk = M[k * ld + k], a = ui[k], c = uj[k];
             const double va = rii - a * a / mkk, vb = rjj - c * c / mkk, vab = rij - a * c / mkk;
             if (mkk == 0.0 || va * vb == 0.0) singular = true;
@@ -100,7 +112,7 @@ __global__ void __launch_bounds__(64) sepselect_kernel(SepBatch b, int cap)
             if (z <= best)
             {  // ties go to the later candidate of the iteration order, as `<=` does in the reference's loop
                 best = z;
-                pick = k;
+                pick = q;
             }
         }
         for (int o = 32; o > 0; o >>= 1)
@@ -128,30 +140,42 @@ __global__ void __launch_bounds__(64) sepselect_kernel(SepBatch b, int cap)
         if (separated && !indep) break;
         separated = separated || indep;
         previous = best;
-        if (lane == 0) b.sel[c0 + len] = b.cand[c0 + pick];
+        const int kp = rem[pick];
+        if (lane == 0) b.sel[c0 + len] = b.cand[c0 + kp];
         len++;
-        if (size == t) break;
-        // ---- rank-1 downdate by the accepted variable ----
-        const double piv = M[pick * ld + pick], ai = ui[pick], aj = uj[pick];
-        for (int k = lane; k < t; k += 64) col[k] = M[k * ld + pick];
-        __syncthreads();
+        if (r == 1) break;
+        // ---- drop it from the list (order kept), then the rank-1 downdate of what remains ----
+        const double piv = M[kp * ld + kp], ai = ui[kp], aj = uj[kp];
+        for (int base = 0; base < r; base += 64)
+        {  // chunks ascend, so a chunk reads its upper neighbour's first entry before that chunk overwrites it
+            const int q = base + lane;
+            const int moved = (q >= pick && q + 1 < r) ? rem[q + 1] : -1;
+            __syncthreads();
+            if (moved >= 0) rem[q] = moved;
+            __syncthreads();
+        }
+        const int r1 = r - 1;
         rii -= ai * ai / piv;
         rjj -= aj * aj / piv;
         rij -= ai * aj / piv;
-        for (int k = lane; k < t; k += 64)
+        for (int q = lane; q < r1; q += 64)
         {
-            const double f = col[k] / piv;
-            fcl[k] = f;
+            const int k = rem[q];
+            const double cv = M[k * ld + kp];
+            const double f = cv / piv;
+            col[q] = cv;
+            fcl[q] = f;
             ui[k] -= f * ai;
             uj[k] -= f * aj;
         }
         __syncthreads();
-        for (int e = lane; e < t * t; e += 64)
+        const float inv_r = 1.0f / (float)r1;
+        for (int e = lane; e < r1 * r1; e += 64)
         {
-            const int a = e / t, c = e - a * t;
-            M[a * ld + c] -= fcl[a] * col[c];
+            int qa, qc;
+            split_index(e, r1, inv_r, qa, qc);
+            M[rem[qa] * ld + rem[qc]] -= fcl[qa] * col[qc];
         }
-        if (lane == 0) alive[pick] = 0;
         __syncthreads();
     }
     if (lane == 0)

@@ -69,7 +69,7 @@ def test_long_candidate_lists_every_storage_class(oracle):
     from oracle import sepselect_oracle as SO
 
     rng = np.random.default_rng(7)
-    p, extra = 100, 6
+    p, extra = 140, 6
     n = p + extra
     F = rng.normal(size=(n, 12)) * 0.45
     cov = F @ F.T + np.eye(n)
@@ -78,7 +78,7 @@ def test_long_candidate_lists_every_storage_class(oracle):
     corr = 0.5 * (corr + corr.T)
     np.fill_diagonal(corr, 1.0)
     alpha, N = 1e-3, 400
-    sizes = [0, 1, 8, 9, 17, 33, 65, 84, 85, 100]
+    sizes = [0, 1, 8, 9, 17, 33, 65, 84, 85, 100, 129, 140]
     pair_i, pair_j, cands = [], [], []
     for k, t in enumerate(sizes):
         i, j = p + (k % extra), p + ((k + 1) % extra)
