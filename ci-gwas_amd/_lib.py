@@ -43,6 +43,7 @@ SYMBOLS = {
     "cusk_last_error": (C.c_char_p, [_vp]),
     "cusk_engine_set_option": (_i, [_vp, C.c_char_p, _ll]),
     "cusk_engine_stream": (_vp, [_vp]),
+    "cusk_engine_set_row_shard": (_i, [_vp, _i, _i, _vp, _vp, _i]),
     "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
     "cusk_result_n": (_i, [_vp]),
@@ -64,6 +65,9 @@ SYMBOLS = {
     "cusk_dev_upload": (_i, [_vp, _vp, _sz]),
     "cusk_dev_download": (_i, [_vp, _vp, _sz]),
 }
+
+# cusk_exchange_fn of include/cusk_hip.h
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p)
 
 _lib = None
 

@@ -102,6 +102,16 @@ struct cusk_engine
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
 
+    // row-sharded sweep of ONE block over several engines: this engine runs the tests of rows
+    // X with X % shard_world == shard_rank and joins the others through an element-wise unsigned MIN of the
+    // per-slot selection state after every level's sweep
+    int shard_rank = 0, shard_world = 1;
+    int shard_host_staging = 0;
+    cusk_exchange_fn shard_fn = nullptr;
+    void *shard_user = nullptr;
+    void *shard_host = nullptr;  // pinned staging buffer
+    size_t shard_host_cap = 0;
+
     // correlation build scratch
     cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev;
     hipEvent_t ev_corr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};

@@ -102,6 +102,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     std::memset(&local, 0, sizeof(local));
     const bool het = (a.mode == 1 && a.Ness != nullptr);
     const int last_level = std::min(kML, a.maxlevel);
+    const bool sharded = e->shard_world > 1;
+    if (sharded && a.mode != 0) return fail(e, CUSK_ERR_ARG, "row sharding supports Skeleton semantics only");
+    if (sharded && !e->shard_fn) return fail(e, CUSK_ERR_ARG, "row sharding needs an exchange function");
 
     const size_t bm = sizeof(unsigned long long) * (size_t)n * words;
     CUSK_HIP(e, e->adj.ensure(bm));
@@ -166,7 +169,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
-                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->ev_main[0], e->ev_main[1], s));
+                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->ev_main[0], e->ev_main[1],
+                                           e->shard_rank, e->shard_world, sharded, s));
             rows_timed = true;
             return CUSK_OK;
         }
@@ -216,6 +220,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // a level whose recheck queue overflowed is redone on the exact path (everything the fast
     // pass recorded is a certified verdict and stays valid); returns 1 when it had to
     auto redo_if_overflowed = [&](int l) -> int {
+        if (sharded) return 0;  // sharded runs settle an overflow inside the level, before the exchange
         if (l < 2 || !plan[l].use_fast || plan[l].redone) return 0;
         if (e->hcnt[l].qcount <= (unsigned long long)e->opt_queue_cap) return 0;
         plan[l].redone = true;
@@ -225,6 +230,55 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         rc = launch_level_finalize(l);
         if (rc != CUSK_OK) return -rc;
         return 1;
+    };
+
+    // row-sharded runs: join the engines' selection state after a level's sweep (unsigned MIN), then derive what the
+    // sweep kernels would have left behind on a single engine
+    auto shard_join = [&](int l) -> int {
+        LevelPlan &pl = plan[l];
+        if (pl.use_fast && l >= 2)
+        {  // a recheck queue that overflowed on this engine: finish its rows on the exact path now (local decision)
+            CUSK_HIP(e, hipMemcpyAsync(e->hcnt + l, dcnt + l, sizeof(LevelCounters), hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+            if (e->hcnt[l].qcount > (unsigned long long)e->opt_queue_cap)
+            {
+                pl.redone = true;
+                local.exact_fallbacks++;
+                const int rc = launch_level_sweeps(l, true);
+                if (rc != CUSK_OK) return rc;
+            }
+        }
+        const size_t count = (size_t)e->hcnt[l].total_edges;
+        const int elem = pl.use_rows ? 4 : 8;
+        void *dev = pl.use_rows ? e->sel.p : e->best[l & 1].p;
+        int rc = 0;
+        if (e->shard_host_staging)
+        {
+            const size_t bytes = count * (size_t)elem;
+            if (bytes > e->shard_host_cap)
+            {
+                if (e->shard_host) (void)hipHostFree(e->shard_host);
+                e->shard_host = nullptr;
+                e->shard_host_cap = 0;
+                CUSK_HIP(e, hipHostMalloc(&e->shard_host, std::max<size_t>(bytes, 64)));
+                e->shard_host_cap = std::max<size_t>(bytes, 64);
+            }
+            CUSK_HIP(e, hipMemcpyAsync(e->shard_host, dev, bytes, hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+            rc = e->shard_fn(e->shard_user, l, e->shard_host, count, elem, 0, (void *)s);
+            if (rc == 0) CUSK_HIP(e, hipMemcpyAsync(dev, e->shard_host, bytes, hipMemcpyHostToDevice, s));
+        }
+        else
+        {
+            CUSK_HIP(e, hipStreamSynchronize(s));
+            rc = e->shard_fn(e->shard_user, l, dev, count, elem, 1, (void *)s);
+        }
+        if (rc != 0) return fail(e, CUSK_ERR_ARG, "row-shard exchange failed at level " + std::to_string(l));
+        if (pl.use_rows)
+            CUSK_HIP(e, launch_level1_count(pl.sp, e->sel.as<unsigned>(), s));
+        else
+            CUSK_HIP(e, launch_count_found(pl.sp.off, pl.sp.best, pl.sp.rowfound, n, s));
+        return CUSK_OK;
     };
 
     if (last_level >= 1) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
@@ -252,7 +306,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             bool pair_items = (l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows;
             CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
                                     e->binom.as<unsigned long long>(), chunk,
-                                    staged_classes, pair_items ? 1 : 0, dcnt + l, s));
+                                    staged_classes, pair_items ? 1 : 0, dcnt + l, e->shard_rank, e->shard_world, s));
             if (first_build) CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
             CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
             CUSK_HIP(e, hipEventRecord(e->ev_cnt, s));
@@ -420,6 +474,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         int rc = launch_level_sweeps(l, false);
         if (rc != CUSK_OK) return rc;
         CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
+        if (sharded)
+        {
+            rc = shard_join(l);
+            if (rc != CUSK_OK) return rc;
+        }
         rc = launch_level_finalize(l);
         if (rc != CUSK_OK) return rc;
         CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
@@ -555,6 +614,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
         for (DevBuf *b : {&e->off[k], &e->nbr[k], &e->best[k], &e->rowinfo[k], &e->rowfound[k], &e->recoff[k]}) b->release();
         for (auto &b : e->items[k]) b.release();
     }
+    if (e->shard_host) (void)hipHostFree(e->shard_host);
     if (e->hcnt) (void)hipHostFree(e->hcnt);
     if (e->hflag) (void)hipHostFree(e->hflag);
     for (auto &ev : e->ev_run)
@@ -603,6 +663,19 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_chunk = value;
     else
         return fail(e, CUSK_ERR_ARG, "unknown option " + k);
+    return CUSK_OK;
+}
+
+extern "C" int cusk_engine_set_row_shard(cusk_engine *e, int rank, int world, cusk_exchange_fn fn, void *user, int host_staging)
+{
+    if (!e) return CUSK_ERR_ARG;
+    if (world < 1 || rank < 0 || rank >= world || (world > 1 && !fn))
+        return fail(e, CUSK_ERR_ARG, "cusk_engine_set_row_shard: need 0 <= rank < world and an exchange function");
+    e->shard_rank = rank;
+    e->shard_world = world;
+    e->shard_fn = fn;
+    e->shard_user = user;
+    e->shard_host_staging = host_staging ? 1 : 0;
     return CUSK_OK;
 }
 

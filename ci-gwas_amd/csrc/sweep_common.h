@@ -161,14 +161,19 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
                            int n, int words, int *wpre, hipStream_t st);
 hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, hipStream_t st);
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
+                       int shard_world, hipStream_t st);
+// rowfound[row] = slots of the row whose best is set (after a cross-engine MIN of best, row-sharded runs)
+hipError_t launch_count_found(const int *off, const unsigned long long *best, int *rowfound, int n, hipStream_t st);
 hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
                                  hipStream_t st);
 hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
                            hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t st);
+                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
+                              int shard_world, bool defer_count, hipStream_t st);
+hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

@@ -397,7 +397,8 @@ __device__ __forceinline__ long long prefix_256(const int *__restrict__ in, int 
 // irrelevant: items of a class are independent).  class_items[] ends up holding the class totals.
 __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, int *off, RowInfo *rowinfo, int n, int L,
                                                      const unsigned long long *__restrict__ binom, unsigned long long chunk,
-                                                     int staged_classes, int pair_mode, LevelCounters *cnt)
+                                                     int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
+                                                     int shard_world)
 {
     __shared__ int s_wave[kNumClasses][4];
     __shared__ long long s_base[kNumClasses];
@@ -417,8 +418,8 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
                                                 : (L == 1 ? (unsigned long long)d : binom[(size_t)d * kBinomStride + L]);
         if (nc >= (1ull << 62))
             cnt->overflow = 1;
-        else
-        {
+        else if (shard_world == 1 || row % shard_world == shard_rank)
+        {  // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow check are global)
             int cls = 0;
             while (d > kClassCap[cls]) cls++;
             if (cls >= staged_classes) cls = kNumClasses - 1;
@@ -489,10 +490,11 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
 }
 
 hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, hipStream_t st)
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
+                       int shard_world, hipStream_t st)
 {
     hipLaunchKernelGGL(plan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, deg, off, rowinfo, n, L, binom, chunk,
-                       staged_classes, pair_mode, cnt);
+                       staged_classes, pair_mode, cnt, shard_rank, shard_world);
     return hipGetLastError();
 }
 
@@ -743,6 +745,7 @@ struct RowsParams
     const int4 *meta;
     unsigned *sel;   // level-1 selection state per CSR slot: lowest passing position (Skeleton) / 0 = edge gone (hetcor)
     int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
+    int shard_rank, shard_world;  // row-sharded runs: this engine streams the rows ya with ya % world == rank
 };
 
 constexpr int kRowsThreads = 256;
@@ -806,6 +809,7 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     const int o0 = p.off[ya];
     const int d = p.off[ya + 1] - o0;
     if (d == 0 || ya + 1 >= n) return;
+    if (rp.shard_world > 1 && ya % rp.shard_world != rp.shard_rank) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kRowsThreads >> 6;
     if (tid < 4) s_cnt[tid] = 0ull;
@@ -1111,8 +1115,34 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
     }
 }
 
+hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st)
+{
+    hipLaunchKernelGGL(level1_count_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, p.n, p.slots);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(256) count_found_kernel(const int *__restrict__ off, const unsigned long long *__restrict__ best,
+                                                          int *rowfound, int n)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int o0 = off[row], d = off[row + 1] - o0;
+    int c = 0;
+    for (int k = lane; k < d; k += 64) c += (best[o0 + k] != kNone) ? 1 : 0;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane == 0) rowfound[row] = c;
+}
+
+hipError_t launch_count_found(const int *off, const unsigned long long *best, int *rowfound, int n, hipStream_t st)
+{
+    hipLaunchKernelGGL(count_found_kernel, dim3((n + 3) / 4), dim3(256), 0, st, off, best, rowfound, n);
+    return hipGetLastError();
+}
+
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
-                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, hipStream_t st)
+                              unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
+                              int shard_world, bool defer_count, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -1122,6 +1152,8 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.meta = static_cast<const int4 *>(meta);
     rp.sel = sel;
     rp.use_filter = use_filter ? 1 : 0;
+    rp.shard_rank = shard_rank;
+    rp.shard_world = shard_world;
     const dim3 grid((unsigned)n);
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
@@ -1135,8 +1167,11 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
         hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
     if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode == 0)
-        hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
-                           p.slots);
+    {
+        if (!defer_count)
+            hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
+                               p.slots);
+    }
     else
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
                            p.words, p.slots);

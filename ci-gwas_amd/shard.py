@@ -119,3 +119,52 @@ def gather_results(results: list[BlockResult], device=None, group=None) -> list[
             br, pos = BlockResult.unpack(buf, pos)
             out.append(br)
     return sorted(out, key=lambda b: b.block_index)
+
+
+# ---------------------------------------------------------------------------
+# Row-sharded sweep of ONE block
+# ---------------------------------------------------------------------------
+def unsigned_min_allreduce_(t, group=None):
+    """In-place element-wise UNSIGNED minimum of an int32 / int64 torch tensor across the group.  torch.distributed
+    has no unsigned types: flipping the sign bit maps unsigned order onto signed order ("none" = all ones becomes
+    the largest signed value), so a signed MIN does it."""
+    import torch
+    import torch.distributed as dist
+
+    sign = -(1 << (8 * t.element_size() - 1))
+    t.bitwise_xor_(sign)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    t.bitwise_xor_(sign)
+    return t
+
+
+def make_min_exchange(group=None, device: int | None = None):
+    """The exchange function a row-sharded engine needs (Engine.set_row_shard): host-staged buffers go through
+    the group's CPU backend (gloo); device buffers are copied into a torch tensor on `device` and reduced by the
+    group's device backend (RCCL), then copied back."""
+    import ctypes as C
+
+    import torch
+
+    hip = None
+
+    def exchange(level, buf, count, elem_bytes, on_device, stream):
+        nonlocal hip
+        if count == 0:
+            return 0
+        np_dtype, t_dtype = (np.int32, torch.int32) if elem_bytes == 4 else (np.int64, torch.int64)
+        if not on_device:
+            arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_int32 if elem_bytes == 4 else C.c_int64)), shape=(count,))
+            unsigned_min_allreduce_(torch.from_numpy(arr), group)
+            return 0
+        if hip is None:
+            hip = C.CDLL("libamdhip64.so")
+        t = torch.empty(count, dtype=t_dtype, device=torch.device("cuda", device if device is not None else torch.cuda.current_device()))
+        nbytes = count * elem_bytes
+        if hip.hipMemcpy(C.c_void_p(t.data_ptr()), C.c_void_p(buf), C.c_size_t(nbytes), 3) != 0:
+            return 1
+        unsigned_min_allreduce_(t, group)
+        torch.cuda.synchronize()
+        return 0 if hip.hipMemcpy(C.c_void_p(buf), C.c_void_p(t.data_ptr()), C.c_size_t(nbytes), 3) == 0 else 1
+
+    return exchange

@@ -162,6 +162,31 @@ class Engine:
     def set_option(self, key: str, value: int) -> None:
         self._check(lib().cusk_engine_set_option(self.h, key.encode(), int(value)))
 
+    def set_row_shard(self, rank: int, world: int, exchange=None, host_staging: bool = True) -> None:
+        """Row-sharded sweep of one block over `world` engines (cusk_engine_set_row_shard).  `exchange(level, buf,
+        count, elem_bytes, on_device, stream) -> int` must all-reduce the buffer with an element-wise unsigned MIN
+        (see ci-gwas_amd/shard.py: make_min_exchange)."""
+        from ._lib import EXCHANGE_FN
+
+        if exchange is None:
+            self._exchange_cb = None
+            self._check(lib().cusk_engine_set_row_shard(self.h, 0, 1, None, None, 0))
+            return
+
+        def trampoline(_user, level, buf, count, elem_bytes, on_device, stream):
+            try:
+                return int(exchange(int(level), int(buf), int(count), int(elem_bytes), bool(on_device), stream))
+            except Exception as exc:  # an exception must not unwind through the C frames
+                import traceback
+
+                traceback.print_exc()
+                self._exchange_error = exc
+                return 1
+
+        self._exchange_cb = EXCHANGE_FN(trampoline)  # keep the thunk alive as long as the engine uses it
+        self._check(lib().cusk_engine_set_row_shard(self.h, int(rank), int(world),
+                                                    C.cast(self._exchange_cb, C.c_void_p), None, 1 if host_staging else 0))
+
     @property
     def stream(self) -> int:
         return int(lib().cusk_engine_stream(self.h) or 0)

@@ -124,6 +124,22 @@ const char *cusk_last_error(const cusk_engine *e);
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
 
+/* Row-sharded sweep of ONE block over several engines, normally one per GPU (a single matrix too
+ * large or too slow for one device; the reference has no counterpart, its Skeleton is single-GPU, cuPC-S.cu:42-190).
+ * Every engine of the group holds the whole matrix and calls cusk_run_skeleton with identical arguments; engine
+ * `rank` of `world` runs the conditional-independence tests of the rows X with X % world == rank only.  After each
+ * level's sweep the engines join their per-edge selection state -- the lowest passing conditioning-set rank of every
+ * ordered pair, "none" = all ones -- through `fn`, which must perform an element-wise UNSIGNED MIN all-reduce of
+ * `count` elements of `elem_bytes` (4 at level 1, 8 beyond) across the group, in place, and return 0 once the
+ * result is in the buffer.  Removal of edges, separating-set records and the next level's neighbour lists are then
+ * derived identically on every engine, so all of them finish with the complete result (bit-identical to a
+ * single-engine run).  host_staging = 1: `buf` is a pinned HOST copy (on_device = 0; for CPU collectives such as
+ * gloo); 0: `buf` is the DEVICE buffer itself (on_device = 1; RCCL), the engine's stream is idle during the call and
+ * the callee must have finished with the buffer when it returns.  world = 1 switches sharding off.  Skeleton
+ * semantics only (cusk_run_hetcor refuses a sharded engine). */
+typedef int (*cusk_exchange_fn)(void *user, int level, void *buf, size_t count, int elem_bytes, int on_device, void *stream);
+int cusk_engine_set_row_shard(cusk_engine *e, int rank, int world, cusk_exchange_fn fn, void *user, int host_staging);
+
 /* Level sweep on a matrix already resident in HBM (C_dev: n*n fp32 row-major).
  * cusk_run_skeleton   : `Skeleton` semantics (fixed per-level thresholds Th[0..14] on
  *                       the host, sepsets + pMax recorded sparsely).

@@ -84,3 +84,46 @@ def test_two_rank_gather_writes_the_same_files_as_one_process(tmp_path, oracle, 
                            np.eye(4, dtype=np.float32))
     back, pos = shard.BlockResult.unpack(br.pack(), 0)
     assert pos == br.pack().size and back.sep is None and np.array_equal(back.adj, br.adj) and back.stem == "x_1_2"
+
+
+def _min_worker(rank, world, port, q):
+    import torch
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cigwas_amd import shard
+
+    ok = True
+    for dtype, none, width in ((np.int64, -1, 62), (np.int32, -1, 30)):
+        rng = np.random.default_rng(5)  # same stream on both ranks: rank r keeps column r
+        vals = rng.integers(0, 2 ** width, size=(1000, world)).astype(dtype)
+        vals[rng.random((1000, world)) < 0.4] = none  # "no separating set": all ones
+        mine = vals[:, rank].copy()
+        shard.unsigned_min_allreduce_(torch.from_numpy(mine))
+        un = vals.astype(np.uint64) if dtype == np.int64 else vals.astype(np.uint32)
+        ok = ok and np.array_equal(mine.view(un.dtype), un.min(axis=1))
+    # the exchange function on a host-staged buffer, as the engine hands it over
+    import ctypes as C
+
+    buf = np.array([7, -1, 3, -1, 5] if rank == 0 else [9, -1, 2, 4, -1], np.int64)
+    ex = shard.make_min_exchange()
+    ok = ok and ex(2, buf.ctypes.data, 5, 8, False, None) == 0 and buf.tolist() == [7, -1, 2, 4, 5]
+    q.put(bool(ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_unsigned_min_exchange_of_the_row_sharded_sweep():
+    """the join of a row-sharded level is an element-wise UNSIGNED minimum with all ones = none"""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_min_worker, args=(2, _free_port(), q), nprocs=2, join=True)
+    assert q.get() and q.get()
