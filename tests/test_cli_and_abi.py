@@ -69,6 +69,7 @@ def test_range_checks():
 def _declared_symbols():
     txt = open(os.path.join(ROOT, "include", "cusk_hip.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    txt = re.sub(r"\btypedef\b[^;]*;", "", txt)  # function-pointer typedefs are types, not exports
     names = re.findall(r"\b([A-Za-z_][A-Za-z0-9_]*)\s*\([^;{]*\)\s*;", txt)
     return sorted(set(n for n in names if n not in ("defined",)))
 
