@@ -10,9 +10,10 @@ N = 16,384 individuals, alpha = 1e-4, max level 5; the matrix is produced from
 synthetic packed .bed genotypes by this repo's own correlation build (Kendall-npn
 SNP x SNP, Pearson SNP x trait / trait x trait), exactly what `cusk` feeds its sweep.
 
-N > 1 (torchrun, one rank per GPU): every rank sweeps its own block (LD blocks are
-independent) -> weak scaling; the only exchange is an RCCL all_gather of
-each block's trait rows of the adjacency bitmap (what merging needs), inside the step.
+N > 1 (torchrun, one rank per GPU): every rank sweeps its own blocks (LD blocks are
+independent) -> weak scaling, no collective in the data path; the job's one
+exchange is an RCCL all_gather of every block's trait rows of the adjacency bitmap (what
+merging needs) at the end of the run, inside the timed region.
 
 Prints ONE JSON line on rank 0.
 """
@@ -23,6 +24,10 @@ import sys
 import time
 
 import numpy as np
+
+# before anything initialises HIP: the engine's two streams must not share a hardware queue with RCCL's streams
+# (see ci-gwas_amd/_lib.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -54,9 +59,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="engine option for kernel experiments (cusk_set_option); the default run sets none")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="run the N > 1 exchange path (process group, barrier, all_gather, reductions) even with one rank: "
+                         "rehearses the RCCL code path on a one-GPU box")
     ap.add_argument("--cpu-sample-markers", type=int, default=10000)
     ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (0 = min(16, affinity))")
     args = ap.parse_args()
+    multi = lambda w: w > 1 or args.force_collectives  # noqa: E731
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -72,7 +81,7 @@ def main():
     local_rank = local_rank % max(ndev, 1)
     torch.cuda.set_device(local_rank)
     cdev = "cuda" if args.backend == "nccl" else "cpu"  # where the collectives' tensors live
-    if world > 1:
+    if multi(world):
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -104,33 +113,51 @@ def main():
     th_het = cg.hetcor_threshold(args.alpha)
 
     words = (n + 63) // 64
-    if world > 1:
-        gather_out = [torch.empty((p, words), dtype=torch.int64, device=cdev) for _ in range(world)]
+    if multi(world):
+        # LD blocks are independent problems: no collective in the data path.  What the job exchanges is
+        # each block's reduced result -- here its trait rows of the adjacency bitmap, what merging needs -- gathered
+        # ONCE for all blocks of the run (as ci-gwas_amd/shard.py does with the per-block files), inside the timed
+        # region.  Per block only a device-to-device copy on the engine's own stream is added.
         import ctypes as C
 
+        from cigwas_amd._lib import lib as _lib
+
         hip = C.CDLL("libamdhip64.so")
+        slots = max(args.steps, args.warmup, 1)
+        stage = torch.zeros((slots, p, words), dtype=torch.int64, device=cdev)
+        gathered = [torch.empty_like(stage) for _ in range(world)]
+        hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    nstep = [0]
 
     def step():
         if args.engine == "cusk":
             st = eng.run_skeleton(Cd.ptr, n, Th, args.max_level)
         else:
             st = eng.run_hetcor(Cd.ptr, n, th_het, args.max_level, ess_uniform=float(N))
-        if world > 1:
-            # the block's trait rows of the adjacency bitmap -> every rank (rank 0 merges)
-            from cigwas_amd._lib import lib as _lib
-
+        if multi(world):
+            k = nstep[0] % slots
+            nstep[0] += 1
             base = _lib().cusk_result_adj_bits_dev(eng.h)
-            rows = torch.empty((p, words), dtype=torch.int64, device=cdev)
-            # kind 3 = device to device, 2 = device to host
-            rc = hip.hipMemcpy(C.c_void_p(rows.data_ptr()), C.c_void_p(base + 8 * words * m), C.c_size_t(8 * words * p),
-                               3 if cdev == "cuda" else 2)
+            dst = stage.data_ptr() + k * 8 * words * p
+            if cdev == "cuda":  # ordered before the next sweep (which overwrites the bitmap) by the engine's stream
+                rc = hip.hipMemcpyAsync(dst, base + 8 * words * m, 8 * words * p, 3, eng.stream)
+            else:  # host staging for the gloo rehearsal: kind 2 = device to host
+                rc = hip.hipMemcpy(C.c_void_p(dst), C.c_void_p(base + 8 * words * m), C.c_size_t(8 * words * p), 2)
             assert rc == 0, f"hipMemcpy failed: {rc}"
-            dist.all_gather(gather_out, rows)
         return st
+
+    def drain():
+        """the job's one exchange: every rank's per-block results to every rank (rank 0 merges)"""
+        if multi(world):
+            nstep[0] = 0
+            if cdev == "cuda":
+                assert hip.hipStreamSynchronize(C.c_void_p(eng.stream)) == 0
+            dist.all_gather(gathered, stage)
 
     for _ in range(args.warmup):
         st = step()
-    if world > 1:
+    drain()
+    if multi(world):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -144,11 +171,17 @@ def main():
         kernel_ms += np.array(st.kernel_ms)
         main_ms += np.array(st.main_kernel_ms)
         level_ms += np.array(st.level_ms)
+    t_steps = time.perf_counter() - t0
+    drain()  # the exchange belongs to the job: inside the timed region
     torch.cuda.synchronize()
-    if world > 1:
+    t_drain = time.perf_counter() - t0
+    if multi(world):
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if os.environ.get("BENCH_DEBUG"):
+        print(f"[rank {rank}] steps {t_steps * 1e3:.3f} ms, +exchange {t_drain * 1e3:.3f} ms, +barrier {dt * 1e3:.3f} ms",
+              file=sys.stderr, flush=True)
+    if multi(world):
         t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -267,7 +300,7 @@ def main():
         print(json.dumps(out))
     Cd.free()
     eng.close()
-    if world > 1:
+    if multi(world):
         dist.destroy_process_group()
 
 

@@ -5,6 +5,12 @@ from __future__ import annotations
 import ctypes as C
 import os
 
+# The engine overlaps independent kernels on two HIP streams.  HIP multiplexes a process's streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4); once RCCL has created its own streams in the same process the
+# engine's two end up sharing one queue and serialise (measured: +13 % per block).  Read at HIP initialisation, so it
+# has to be in the environment before the first HIP call of the process.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "csrc", "libcusk_hip.so")
 ML = 14
