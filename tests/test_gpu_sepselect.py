@@ -117,3 +117,30 @@ def test_singular_submatrix_exits_like_reference(tmp_path):
     corr[0, 1] = corr[1, 0] = 1.0  # traits 0 and 1 identical: the first round's pivot is fine, the second is 0
     _, _, flags, _ = eng.sepselect_greedy(corr[:, :2], [3], [4], [0.0], [0, 2], [0, 1], [9.0, 9.0, 9.0])
     assert flags[0] >> 8 == 2
+
+
+def test_host_mirror_exits_on_singular_like_the_reference(tmp_path):
+    """sepselect.py:8-18: a singular sub-matrix ends the reference with sys.exit(); two identical traits do that"""
+    import scipy.sparse as sp
+    from scipy.io import mmwrite
+
+    from cigwas_amd import sepselect as SS
+
+    p, m = 3, 2
+    n = p + m
+    corr = np.eye(n)
+    corr[0, 1] = corr[1, 0] = 1.0  # traits 0 and 1 are the same variable
+    for t in (0, 1, 2):
+        for v in (3, 4):
+            corr[t, v] = corr[v, t] = 0.3 if t < 2 else 0.2
+    corr[0, 2] = corr[2, 0] = corr[1, 2] = corr[2, 1] = 0.25
+    adj = corr != 0
+    np.fill_diagonal(adj, False)
+    adj[3, 4] = adj[4, 3] = False  # markers 3 and 4: unshielded through the traits
+    stem = os.path.join(str(tmp_path), "all_merged")
+    mmwrite(stem + "_sam.mtx", sp.coo_matrix(adj.astype(np.int32)))
+    mmwrite(stem + "_scm.mtx", sp.coo_matrix(corr))
+    open(stem + ".mdim", "w").write(f"{n}\t{p}\t3\n")
+    np.arange(m, dtype=np.int32).tofile(stem + ".ixs")
+    with pytest.raises(SystemExit):
+        SS.sepselect_merged(stem, 1e-4, 1000)

@@ -70,3 +70,15 @@ def test_host_graph_logic_matches_reference_files(name, tmp_path):
     assert np.array_equal(g["adj"], cr.adj) and np.array_equal(g["corr"], cr.corr) and np.array_equal(g["ixs"], cr.ixs)
     assert SO.unshielded_triples(g["adj"]) == cr.get_unshielded_triples()
     assert list(SO.unshielded_triples(g["adj"])) == list(cr.get_unshielded_triples())  # same iteration order
+
+
+def test_asymmetric_trait_block_is_refused_before_any_device_work(tmp_path):
+    """the device kernel assumes corr[v, t] == corr[t, v]; the host mirror checks instead of guessing"""
+    from cigwas_amd import sepselect as SS
+
+    case = load_cases()["small"]
+    stem, _ = materialise(case, str(tmp_path))
+    cr = SS.MergedCuskResults(stem)
+    cr.corr[0, 1] += 0.25
+    with pytest.raises(ValueError, match="not symmetric"):
+        cr.find_maximal_and_min_pcorr_sepsets_incr(case["alpha"], case["num_samples"])
