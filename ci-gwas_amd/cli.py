@@ -2,7 +2,7 @@
 """`ci-gwas.py`-compatible command line for the cusk path on MI355X.
 
 Mirrors the reference's workflow CLI for the two GPU subcommands
-(/root/reference/ci-gwas.py:63-92 `block`, :64-93 `cusk`, :95-253 `cuskss`, handlers :404-456): same
+(/root/reference/ci-gwas.py:54-61 `prep-bed`, :63-92 `block`, :64-93 `cusk`, :95-253 `cuskss`, handlers :404-456): same
 positional / optional arguments, same range checks, same conversion to the positional argv of
 the native `mps` program with literal 'NULL' for absent paths, `subprocess.run(check=True)`.
 `cuskss-het` and `cuskss-merged` (README.md:65,75 of the reference names them, its CLI does
@@ -61,6 +61,13 @@ def _add_cusk(sub):
     p.set_defaults(func=cusk)
 
 
+def _add_prep(sub):
+    """ci-gwas.py:54-61"""
+    p = sub.add_parser("prep-bed", help="Prepare PLINK bed file for cusk")
+    p.add_argument("bfiles", type=str, help="filestem of .bed, .bim, .fam fileset")
+    p.set_defaults(func=prep_bed)
+
+
 def _add_block(sub):
     """ci-gwas.py:63-92"""
     p = sub.add_parser("block", help="Tile whole-genome LD matrix into block diagonal matrix (requires GPU)")
@@ -116,6 +123,7 @@ def _add_sepselect(sub):
 def build_parser() -> argparse.ArgumentParser:
     parser = _Parser(prog="ci-gwas", description="cusk / cuskss steps of CI-GWAS on AMD Instinct MI355X")
     sub = parser.add_subparsers(required=True, title="subcommands")
+    _add_prep(sub)
     _add_block(sub)
     _add_cusk(sub)
     _add_cuskss(sub, "cuskss", "Infer skeleton using summary statistic data (requires GPU)")
@@ -123,6 +131,11 @@ def build_parser() -> argparse.ArgumentParser:
     _add_cuskss(sub, "cuskss-merged", "cuskss on the union of markers selected in all blocks: needs --marker-indices")
     _add_sepselect(sub)
     return parser
+
+
+def prep_bed(args):
+    """ci-gwas.py:386-387"""
+    subprocess.run([MPS_PATH, "prep", args.bfiles], check=True)
 
 
 def block_argv(args) -> list[str]:

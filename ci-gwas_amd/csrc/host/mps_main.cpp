@@ -544,7 +544,7 @@ commands:
     cusk                    Run the skeleton search on a single block of block diagonal genomic covariance matrix
     cuskss                  Run the skeleton search on a block of markers and traits with pre-computed correlations.
     block                   Tile the marker x marker correlation matrix of every chromosome into LD blocks
-    prep                    not part of the MI355X build: use the reference's CPU tool and pass its output files
+    prep                    Prepare input (PLINK) .bed file for cusk: .dim, .means, .stds, .modes
 )";
 
 }  // namespace
@@ -639,6 +639,101 @@ int cmd_block(int argc, char **argv)
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------
+// mps prep   (cli.cpp:680-708, prep.cpp:15-76 compute_bed_col_stats_no_impute, :159-203 prep_bed_no_impute)
+// ---------------------------------------------------------------------------------------
+// Per marker over its non-missing genotypes: mean = sum / (float)count, population standard deviation with the
+// squared deviations accumulated in single precision in sample order, most frequent genotype (ties to the lower
+// one).  Host code like the reference's (one streaming pass over the .bed; nothing here is worth a device launch);
+// the arithmetic is kept operation for operation because cusk's Pearson correlations divide by these numbers.
+const char *PREP_USAGE = R"(
+Prepare input (PLINK) .bed file for cusk
+
+usage: mps prep <.bfiles>
+
+arguments:
+    .bfiles filestem of .bed, .bim, .fam fileset
+)";
+
+int cmd_prep(int argc, char **argv)
+{
+    if (argc != 3 || std::string(argv[2]) == "--help" || std::string(argv[2]) == "-h")
+    {
+        std::cout << PREP_USAGE << std::endl;
+        std::exit(1);
+    }
+    const std::string bfiles = argv[2];
+    for (const char *sfx : {".bed", ".bim", ".fam"}) check_path(bfiles + sfx);
+    if (!bed_has_valid_magic(bfiles + ".bed"))
+    {
+        std::cout << "Invalid prefix bytes in bed" << std::endl;
+        std::exit(1);
+    }
+    const size_t N = count_lines(bfiles + ".fam");
+    const size_t M = count_lines(bfiles + ".bim");
+    std::cout << "Writing dim file." << std::endl;
+    {
+        std::ofstream fout(bfiles + ".dim");
+        fout << N << "\t" << M << std::endl;
+    }
+    const size_t bytes_per_marker = (N + 3) / 4;
+    std::vector<unsigned char> col(bytes_per_marker);
+    std::vector<float> means, stds;
+    std::vector<int> modes;
+    std::ifstream bed(bfiles + ".bed", std::ios::binary);
+    bed.seekg(3);
+    std::cout << "Computing means, stds, modes." << std::endl;
+    // PLINK codes, low bits first (bed_lut.h): 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0
+    static const int kValue[4] = {2, 0, 1, 0};
+    size_t lc = 0;
+    while (bed.read(reinterpret_cast<char *>(col.data()), (std::streamsize)bytes_per_marker))
+    {
+        if (lc % 100000 == 0) std::cout << "Processing marker " << lc + 1 << " / " << M << std::endl;
+        int counts[3] = {0, 0, 0};
+        size_t sum = 0, missing = 0;
+        for (size_t i = 0; i < N; i++)
+        {
+            const int code = (col[i >> 2] >> (2 * (i & 3))) & 3;
+            if (code == 1)
+                missing++;
+            else
+            {
+                counts[kValue[code]]++;
+                sum += (size_t)kValue[code];
+            }
+        }
+        int mode = 0;
+        for (int g = 1; g < 3; g++)
+            if (counts[g] > counts[mode]) mode = g;
+        const float mean = sum / (float)(N - missing);
+        float ss = 0.0f;
+        for (size_t i = 0; i < N; i++)
+        {
+            const int code = (col[i >> 2] >> (2 * (i & 3))) & 3;
+            if (code != 1) ss += ((float)kValue[code] - mean) * ((float)kValue[code] - mean);
+        }
+        means.push_back(mean);
+        stds.push_back(std::sqrt(ss / (float)(N - missing)));
+        modes.push_back(mode);
+        lc++;
+    }
+    std::cout << "Writing stats to files." << std::endl;
+    {
+        std::ofstream f(bfiles + ".means");
+        for (float v : means) f << v << std::endl;
+    }
+    {
+        std::ofstream f(bfiles + ".stds");
+        for (float v : stds) f << v << std::endl;
+    }
+    {
+        std::ofstream f(bfiles + ".modes");
+        for (int v : modes) f << v << std::endl;
+    }
+    std::cout << "Done." << std::endl;
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc == 1)
@@ -650,12 +745,7 @@ int main(int argc, char **argv)
     if (cmd == "cusk") return cmd_cusk(argc, argv);
     if (cmd == "cuskss") return cmd_cuskss(argc, argv);
     if (cmd == "block") return cmd_block(argc, argv);
-    if (cmd == "prep")
-    {
-        std::cerr << "mps " << cmd << ": outside the scope of this build (SURVEY.md 2.1); its output files are consumed as is"
-                  << std::endl;
-        return EXIT_FAILURE;
-    }
+    if (cmd == "prep") return cmd_prep(argc, argv);
     std::cout << MPS_USAGE << std::endl;
     return EXIT_SUCCESS;
 }

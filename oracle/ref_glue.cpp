@@ -12,6 +12,7 @@
 #include <mps/marker_trait_summary_stats.h>
 #include <mps/parent_set.h>
 #include <mps/phen.h>
+#include <mps/prep.h>
 #include <mps/trait_summary_stats.h>
 
 #include <cstring>
@@ -175,6 +176,9 @@ extern "C"
         }
         return (int)b.size();
     }
+
+    // prep.cpp:159-203 (`mps prep`): writes <stem>.dim/.means/.stds/.modes next to the bfiles
+    void ref_prep(const char *stem) { prep_bed_no_impute(BfilesBase(std::string(stem))); }
 
     // blocking.cpp:13-35
     void ref_hanning_smoothing(const float *v, int n, int window_size, double *out)

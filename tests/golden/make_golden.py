@@ -144,6 +144,13 @@ kat["cuskss_two_stage_block"] = dict(common, max_level_two=1, merged=False, trai
                                      exp_ixs=[int(v) for v in array(b, "exp_ixs")],
                                      exp_adj=[int(v) for v in array(b, "exp_adj")], exp_corr=array(b, "exp_corr"), tol=0.001)
 
+# ---- prep_tests.cpp:46-68 (mps prep on tests/test_files/small.*) ---------------------------------------------
+pt = strip_comments(read("tests/prep_tests.cpp"))
+b = test_body(pt, "ParseBed", "CorrectOutFilesGenerated")
+kat["prep_small"] = {"stem": "small", "exp_stds": array(b, "one_stds_exp"), "exp_means": array(b, "one_means_exp"),
+                     "exp_dims": [int(v) for v in re.search(r"BedDims\s+exp\(\s*(\d+)\s*,\s*(\d+)\s*\)", b).groups()],
+                     "tol": 0.000001}
+
 with open(os.path.join(HERE, "ref_kat.json"), "w") as f:
     json.dump(kat, f, indent=1)
 

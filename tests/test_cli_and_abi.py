@@ -113,3 +113,11 @@ def test_sepselect_subcommands_match_reference_arguments():
     assert a.func is cli.run_sepselect and not hasattr(a, "orientation_prior")
     with pytest.raises(SystemExit):
         p.parse_args(["sepselect", "out/all_merged", "1.5", "1000"])  # alpha outside (0, 1)
+
+
+def test_prep_bed_subcommand():
+    """ci-gwas.py:54-61, :386-387"""
+    from cigwas_amd import cli
+
+    a = cli.build_parser().parse_args(["prep-bed", "data/chr"])
+    assert a.bfiles == "data/chr" and a.func is cli.prep_bed

@@ -193,3 +193,49 @@ def test_blocking_matches_reference_code(oracle, ref, seed, n, maxb):
     assert k > 0
     assert oracle.block_chr(v, maxb) == [(int(first[i]), int(last[i])) for i in range(k)]
 
+
+
+def _prep_inputs(tmp_path, synth, golden_dir, which):
+    """bfiles for `mps prep`: the reference's own small.* or a synthetic set with missing genotypes"""
+    import shutil
+
+    d = tmp_path / which
+    d.mkdir()
+    stem = str(d / "x")
+    if which == "small":
+        for sfx in (".bed", ".bim", ".fam"):
+            shutil.copy(os.path.join(golden_dir, "small" + sfx), stem + sfx)
+    else:
+        N = 1003  # not a multiple of four: the last byte of every marker is partly padding
+        G = synth.make_genotypes(300, N, np.random.default_rng(5), miss=0.02)
+        mu, sd = synth.bed_stats(G)
+        synth.write_bfiles(stem, synth.pack_bed(G), N, mu, sd)
+        for sfx in (".dim", ".means", ".stds"):
+            os.remove(stem + sfx)
+    return stem
+
+
+@pytest.mark.parametrize("which", ["small", "synthetic"])
+def test_mps_prep_writes_the_reference_files(ref, kat, synth, golden_dir, tmp_path, which):
+    """`mps prep` of this build (host code, runs without a GPU) against the reference's prep.cpp compiled in place:
+    .dim/.means/.stds/.modes byte for byte; on small.* also the values the reference's prep_tests.cpp expects"""
+    import subprocess
+
+    from cigwas_amd.cli import MPS_PATH
+
+    if not os.path.exists(MPS_PATH):
+        pytest.skip("mps not built")
+    ours = _prep_inputs(tmp_path, synth, golden_dir, which)
+    theirs = ours + "_ref"
+    for sfx in (".bed", ".bim", ".fam"):
+        os.link(ours + sfx, theirs + sfx)
+    subprocess.run([MPS_PATH, "prep", ours], check=True, capture_output=True)
+    ref.ref_prep.restype = None
+    ref.ref_prep(theirs.encode())
+    for sfx in (".dim", ".means", ".stds", ".modes"):
+        assert open(ours + sfx, "rb").read() == open(theirs + sfx, "rb").read(), sfx
+    if which == "small":
+        k = kat["prep_small"]
+        assert np.allclose(np.loadtxt(ours + ".means"), k["exp_means"], atol=k["tol"], rtol=0)
+        assert np.allclose(np.loadtxt(ours + ".stds"), k["exp_stds"], atol=k["tol"], rtol=0)
+        assert open(ours + ".dim").read().split() == [str(v) for v in k["exp_dims"]]
