@@ -108,8 +108,6 @@ def _min_worker(rank, world, port, q):
         un = vals.astype(np.uint64) if dtype == np.int64 else vals.astype(np.uint32)
         ok = ok and np.array_equal(mine.view(un.dtype), un.min(axis=1))
     # the exchange function on a host-staged buffer, as the engine hands it over
-    import ctypes as C
-
     buf = np.array([7, -1, 3, -1, 5] if rank == 0 else [9, -1, 2, 4, -1], np.int64)
     ex = shard.make_min_exchange()
     ok = ok and ex(2, buf.ctypes.data, 5, 8, False, None) == 0 and buf.tolist() == [7, -1, 2, 4, 5]
