@@ -13,6 +13,7 @@
 //   Schur complement .... :685-696, :829-850
 // Float `log` is the correctly rounded one, (float)log((double)x).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 
 namespace cusk {
@@ -475,6 +476,323 @@ __device__ __forceinline__ void pinv_svd_core(Arr A, Arr V, Arr w, Arr rv1, floa
 #undef VV
 }
 
+// compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F &&f)
+{
+    if constexpr (I < N)
+    {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// The same svdcmp for small M (4, 5: the levels of the headline workload) with every array index known at compile
+// time, so that the matrices live in registers: the LDS form above pays ~64 cycles of LDS latency for almost every
+// one of its few thousand dependent operations, which made a single pseudo-inverse ~40 us -- and a level's recheck
+// pass or its winners' z is exactly one such chain long.  Loops whose bounds depend on data (the search for l, the
+// rotations from l to k) run over their full static range under a predicate; the operations that execute, and
+// their order, are those of pinv_svd_core, so the result is bit-identical.
+template <int M>
+__device__ __forceinline__ void pinv_svd_static(const float *m2, float *Inv)
+{
+    float a[M][M], v[M][M], w[M], rv1[M];
+#pragma unroll
+    for (int r = 0; r < M; r++)
+#pragma unroll
+        for (int q = 0; q < M; q++)
+        {
+            a[r][q] = m2[r * M + q];
+            v[r][q] = 0.0f;
+        }
+    float anorm = 0.0f, g = 0.0f, scale = 0.0f, s = 0.0f, f, h;
+    // Householder reduction to bidiagonal form
+    static_for<0, M>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;
+        constexpr int l = i + 1;
+        rv1[i] = scale * g;
+        g = s = scale = 0.0f;
+#pragma unroll
+        for (int k = i; k < M; k++) scale += fabsf(a[k][i]);
+        if (scale != 0.0f)
+        {
+#pragma unroll
+            for (int k = i; k < M; k++)
+            {
+                a[k][i] = (a[k][i] / scale);
+                s += (a[k][i] * a[k][i]);
+            }
+            f = a[i][i];
+            g = -sgn_of(sqrtf(s), f);
+            h = f * g - s;
+            a[i][i] = f - g;
+            if constexpr (i != M - 1)
+            {
+#pragma unroll
+                for (int j = l; j < M; j++)
+                {
+                    s = 0.0f;
+#pragma unroll
+                    for (int k = i; k < M; k++) s += (a[k][i] * a[k][j]);
+                    f = s / h;
+#pragma unroll
+                    for (int k = i; k < M; k++) a[k][j] += (f * a[k][i]);
+                }
+            }
+#pragma unroll
+            for (int k = i; k < M; k++) a[k][i] = (a[k][i] * scale);
+        }
+        w[i] = scale * g;
+        g = s = scale = 0.0f;
+        if constexpr (i != M - 1)
+        {
+#pragma unroll
+            for (int k = l; k < M; k++) scale += fabsf(a[i][k]);
+            if (scale != 0.0f)
+            {
+#pragma unroll
+                for (int k = l; k < M; k++)
+                {
+                    a[i][k] = (a[i][k] / scale);
+                    s += (a[i][k] * a[i][k]);
+                }
+                f = a[i][l];
+                g = -sgn_of(sqrtf(s), f);
+                h = f * g - s;
+                a[i][l] = f - g;
+#pragma unroll
+                for (int k = l; k < M; k++) rv1[k] = a[i][k] / h;
+#pragma unroll
+                for (int j = l; j < M; j++)
+                {
+                    s = 0.0f;
+#pragma unroll
+                    for (int k = l; k < M; k++) s += (a[j][k] * a[i][k]);
+#pragma unroll
+                    for (int k = l; k < M; k++) a[j][k] += (s * rv1[k]);
+                }
+#pragma unroll
+                for (int k = l; k < M; k++) a[i][k] = a[i][k] * scale;
+            }
+        }
+        const float cand = fabsf(w[i]) + fabsf(rv1[i]);
+        anorm = (anorm > cand) ? anorm : cand;
+    });
+    // accumulation of the right-hand transformations (i = M-1 .. 0; l = i + 1 whenever it is used)
+    static_for<0, M>([&](auto rc) {
+        constexpr int i = M - 1 - decltype(rc)::value;
+        constexpr int l = i + 1;
+        if constexpr (i < M - 1)
+        {
+            if (g != 0.0f)
+            {
+#pragma unroll
+                for (int j = l; j < M; j++) v[j][i] = (a[i][j] / a[i][l]) / g;
+#pragma unroll
+                for (int j = l; j < M; j++)
+                {
+                    s = 0.0f;
+#pragma unroll
+                    for (int k = l; k < M; k++) s += (a[i][k] * v[k][j]);
+#pragma unroll
+                    for (int k = l; k < M; k++) v[k][j] += (s * v[k][i]);
+                }
+            }
+#pragma unroll
+            for (int j = l; j < M; j++) v[i][j] = v[j][i] = 0.0f;
+        }
+        v[i][i] = 1.0f;
+        g = rv1[i];
+    });
+    // accumulation of the left-hand transformations
+    static_for<0, M>([&](auto rc) {
+        constexpr int i = M - 1 - decltype(rc)::value;
+        constexpr int l = i + 1;
+        g = w[i];
+#pragma unroll
+        for (int j = l; j < M; j++) a[i][j] = 0.0f;
+        if (g != 0.0f)
+        {
+            g = (float)(1.0 / (double)g);
+            if constexpr (i != M - 1)
+            {
+#pragma unroll
+                for (int j = l; j < M; j++)
+                {
+                    s = 0.0f;
+#pragma unroll
+                    for (int k = l; k < M; k++) s += (a[k][i] * a[k][j]);
+                    f = (s / a[i][i]) * g;
+#pragma unroll
+                    for (int k = i; k < M; k++) a[k][j] += (f * a[k][i]);
+                }
+            }
+#pragma unroll
+            for (int j = i; j < M; j++) a[j][i] = (a[j][i] * g);
+        }
+        else
+        {
+#pragma unroll
+            for (int j = i; j < M; j++) a[j][i] = 0.0f;
+        }
+        a[i][i] = a[i][i] + 1.0f;
+    });
+    // diagonalisation of the bidiagonal form, k = M-1 .. 0
+    static_for<0, M>([&](auto rc) {
+        constexpr int k = M - 1 - decltype(rc)::value;
+        for (int its = 0; its < 30; its++)
+        {
+            int flag = 1, l = 0;
+            {  // for (l = k; l >= 0; l--) with its two exits; rv1[0] is always 0, so the search ends at l = 0 at the latest
+                bool found = false;
+#pragma unroll
+                for (int ll = k; ll >= 0; ll--)
+                {
+                    if (!found)
+                    {
+                        l = ll;
+                        if (fabsf(rv1[ll]) + anorm == anorm)
+                        {
+                            flag = 0;
+                            found = true;
+                        }
+                        else if (ll > 0 && fabsf(w[ll > 0 ? ll - 1 : 0]) + anorm == anorm)
+                            found = true;
+                    }
+                }
+            }
+            float c, x, y, z;
+            if (flag)
+            {  // cancellation of rv1[l]; nm = l - 1 >= 0 here
+                const int nm = l - 1;
+                c = 0.0f;
+                s = 1.0f;
+#pragma unroll
+                for (int i = 0; i <= k; i++)
+                {
+                    if (i >= l)
+                    {
+                        f = s * rv1[i];
+                        if (fabsf(f) + anorm != anorm)
+                        {
+                            g = w[i];
+                            h = pythag(f, g);
+                            w[i] = h;
+                            h = (float)(1.0 / (double)h);
+                            c = g * h;
+                            s = (-f * h);
+#pragma unroll
+                            for (int j = 0; j < M; j++)
+                            {
+                                y = 0.0f;
+#pragma unroll
+                                for (int q = 0; q < M; q++)
+                                    if (q == nm) y = a[j][q];
+                                z = a[j][i];
+                                const float ynew = (y * c + z * s);
+#pragma unroll
+                                for (int q = 0; q < M; q++)
+                                    if (q == nm) a[j][q] = ynew;
+                                a[j][i] = (z * c - y * s);
+                            }
+                        }
+                    }
+                }
+            }
+            z = w[k];
+            if (l == k)
+            {
+                if (z < 0.0f)
+                {
+                    w[k] = (-z);
+#pragma unroll
+                    for (int j = 0; j < M; j++) v[j][k] = (-v[j][k]);
+                }
+                break;
+            }
+            if constexpr (k > 0)
+            {
+                constexpr int nm = k - 1;
+                x = 0.0f;
+#pragma unroll
+                for (int q = 0; q <= k; q++)
+                    if (q == l) x = w[q];
+                y = w[nm];
+                g = rv1[nm];
+                h = rv1[k];
+                f = (float)((double)((y - z) * (y + z) + (g - h) * (g + h)) / (2.0 * (double)h * (double)y));
+                g = pythag(f, 1.0f);
+                f = ((x - z) * (x + z) + h * ((y / (f + sgn_of(g, f))) - h)) / x;
+                c = s = 1.0f;
+#pragma unroll
+                for (int j = 0; j <= nm; j++)
+                {
+                    if (j >= l)
+                    {
+                        constexpr int dummy = 0;
+                        (void)dummy;
+                        const int i = j + 1;
+                        g = rv1[i];
+                        y = w[i];
+                        h = s * g;
+                        g = c * g;
+                        z = pythag(f, h);
+                        rv1[j] = z;
+                        c = f / z;
+                        s = h / z;
+                        f = x * c + g * s;
+                        g = g * c - x * s;
+                        h = y * s;
+                        y = y * c;
+#pragma unroll
+                        for (int jj = 0; jj < M; jj++)
+                        {
+                            x = v[jj][j];
+                            z = v[jj][i];
+                            v[jj][j] = (x * c + z * s);
+                            v[jj][i] = (z * c - x * s);
+                        }
+                        z = pythag(f, h);
+                        w[j] = z;
+                        if (z != 0.0f)
+                        {
+                            z = (float)(1.0 / (double)z);
+                            c = f * z;
+                            s = h * z;
+                        }
+                        f = (c * g) + (s * y);
+                        x = (c * y) - (s * g);
+#pragma unroll
+                        for (int jj = 0; jj < M; jj++)
+                        {
+                            y = a[jj][j];
+                            z = a[jj][i];
+                            a[jj][j] = (y * c + z * s);
+                            a[jj][i] = (z * c - y * s);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q <= k; q++)
+                    if (q == l) rv1[q] = 0.0f;
+                rv1[k] = f;
+                w[k] = x;
+            }
+        }
+    });
+    // Inv = (V / w) * U^T ; V(i,k)/w[k] is formed first, as the reference does
+#pragma unroll
+    for (int ii = 0; ii < M; ii++)
+#pragma unroll
+        for (int jj2 = 0; jj2 < M; jj2++)
+        {
+            float acc = 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < M; kk++) acc = acc + (v[ii][kk] / w[kk]) * a[jj2][kk];
+            Inv[ii * M + jj2] = acc;
+        }
+}
+
 template <int M>
 __device__ __noinline__ void pinv_svd(float *A, float *Inv)
 {
@@ -496,6 +814,8 @@ __device__ __forceinline__ void pinv_ref_order(float *M2, float *Inv)
 }
 
 // Per-subset state: inverse of C[S,S] and the X-side products.
+constexpr int kSvdStaticMax = 5;  // conditioning-set sizes whose pseudo-inverse runs from registers
+
 template <int L>
 struct SubsetExact
 {
@@ -537,6 +857,26 @@ struct SubsetExact
 #pragma unroll
             for (int a = 0; a < ((L > 1) ? L * L : 1); a++) tmp[a] = m2[a];
             prepare(tmp, m1x_in);
+        }
+        else if constexpr (L <= kSvdStaticMax)
+        {  // registers instead of the LDS work space (which stays allocated but unused)
+#pragma unroll
+            for (int a = 0; a < L; a++) m1x[a] = m1x_in[a];
+            pinv_svd_static<L>(m2, inv);
+#pragma unroll
+            for (int c2 = 0; c2 < L; c2++)
+            {
+                float acc = 0.0f;
+#pragma unroll
+                for (int c3 = 0; c3 < L; c3++) acc += m1x[c3] * inv[c3 * L + c2];
+                mmx[c2] = acc;
+            }
+            float h = 0.0f;
+#pragma unroll
+            for (int c3 = 0; c3 < L; c3++) h += mmx[c3] * m1x[c3];
+            h00 = h;
+            (void)ws;
+            (void)stride;
         }
         else
         {

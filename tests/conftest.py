@@ -5,6 +5,14 @@ import sys
 
 import pytest
 
+try:
+    # Some GPU tests use torch (synthetic data on the device, process groups) next to the engine.  torch ships its own
+    # copy of the HIP runtime; whichever libamdhip64 is loaded first serves the whole process, and torch does not find
+    # its device when that is the system copy pulled in by libcusk_hip.so.  Loading torch's first works for both.
+    import torch  # noqa: F401
+except Exception:  # the engine itself does not need torch
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
