@@ -1,6 +1,7 @@
 """sepselect_oracle.py -- CPU restatement of the reference's `sepselect` post-processing.
 
-TEST INFRASTRUCTURE ONLY: imported by tests/, tools/ timing scripts and nothing in the product path.
+TEST INFRASTRUCTURE ONLY: imported by tests/ (parity tests and the timing script tests/perf_sepselect.py) and nothing
+in the product path.
 
 What it restates (reference file:line, /root/reference/cusk_postprocessing/sepselect.py):
   * loading a merged skeleton and dropping collinear markers ........ :427-480

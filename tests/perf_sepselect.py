@@ -3,7 +3,10 @@
 `orient_v_structures_merged` call, beside the numpy oracle's greedy loop (the reference's algorithm: one matrix
 inverse per candidate per round) on a bounded sample of the same outer pairs.
 
-Usage: python tools/sepselect_time.py [--traits 40] [--markers 4000] [--sample-pairs 300]
+Lives under tests/ because it runs the oracle (test infrastructure) as the CPU side of the comparison; pytest does
+not collect it.
+
+Usage: python tests/perf_sepselect.py [--traits 40] [--markers 4000] [--sample-pairs 300]
 """
 import argparse
 import json
@@ -14,7 +17,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root
 sys.path.insert(0, ROOT)
 
 
