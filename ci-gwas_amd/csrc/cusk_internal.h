@@ -101,6 +101,7 @@ struct cusk_engine
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
+    long long opt_sep_ws_budget = 4ll << 30;  // HBM work space of cusk_sepselect_greedy for candidate lists beyond LDS
 
     // row-sharded sweep of ONE block over several engines: this engine runs the tests of rows
     // X with X % shard_world == shard_rank and joins the others through an element-wise unsigned MIN of the

@@ -661,6 +661,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)
         e->opt_chunk = value;
+    else if (k == "sepselect_ws_bytes" && value > 0)
+        e->opt_sep_ws_budget = value;
     else
         return fail(e, CUSK_ERR_ARG, "unknown option " + k);
     return CUSK_OK;

@@ -248,7 +248,10 @@ int sepselect_greedy_impl(cusk_engine *e, const double *trait_corr, long long n,
     CUSK_HIP(e, up(d_list, flat.data(), sizeof(int) * flat.size()));
     const size_t nbig = lists[kSepLdsClasses].size();
     const size_t big_bytes = (sep_bytes(max_t) + 15) & ~(size_t)15;
-    if (nbig) CUSK_HIP(e, d_ws.ensure(big_bytes * nbig));
+    // the HBM work space of the long-list pairs is bounded: they run in batches of what fits into the budget (option
+    // "sepselect_ws_bytes", default 4 GiB)
+    const size_t big_batch = std::max<size_t>(1, std::min<size_t>(nbig, (size_t)std::max<long long>(e->opt_sep_ws_budget, 0) / big_bytes));
+    if (nbig) CUSK_HIP(e, d_ws.ensure(big_bytes * big_batch));
 
     SepBatch b;
     b.tc = d_tc.as<double>();
@@ -282,7 +285,14 @@ int sepselect_greedy_impl(cusk_engine *e, const double *trait_corr, long long n,
             hipLaunchKernelGGL(sepselect_kernel<true>, dim3((unsigned)cnt), dim3(64), lds, s, b, kSepCaps[c]);
         }
         else
-            hipLaunchKernelGGL(sepselect_kernel<false>, dim3((unsigned)cnt), dim3(64), 0, s, b, max_t);
+        {
+            for (size_t done = 0; done < cnt; done += big_batch)
+            {  // same stream: a batch reuses the work space after the previous one has finished
+                b.list = d_list.as<int>() + first[c] + done;
+                hipLaunchKernelGGL(sepselect_kernel<false>, dim3((unsigned)std::min(big_batch, cnt - done)), dim3(64), 0, s, b,
+                                   max_t);
+            }
+        }
         CUSK_HIP(e, hipGetLastError());
     }
     CUSK_HIP(e, hipEventRecord(ev1, s));

@@ -98,6 +98,31 @@ def test_long_candidate_lists_every_storage_class(oracle):
         assert bool(flags[k] & 1) == seen
 
 
+def test_many_long_lists_run_in_work_space_batches():
+    """pairs beyond the LDS classes share a bounded HBM work space: many of them give the same answer as one"""
+    import cigwas_amd as cg
+    from cigwas_amd.sepselect import alpha_thr
+
+    rng = np.random.default_rng(3)
+    p = 96
+    n = p + 2
+    F = rng.normal(size=(n, 10)) * 0.4
+    cov = F @ F.T + np.eye(n)
+    sd = np.sqrt(np.diag(cov))
+    corr = 0.5 * (cov / np.outer(sd, sd) + (cov / np.outer(sd, sd)).T)
+    np.fill_diagonal(corr, 1.0)
+    thr = alpha_thr(1e-3, 300, np.arange(p + 1, dtype=np.float64))
+    cand1 = np.arange(p, dtype=np.int32)
+    eng = cg.Engine(0)
+    one = eng.sepselect_greedy(corr[:, :p], [p], [p + 1], corr[[p], [p + 1]], [0, p], cand1, thr)
+    k = 300
+    eng.set_option("sepselect_ws_bytes", 1 << 20)  # ~13 pairs per batch
+    many = eng.sepselect_greedy(corr[:, :p], [p] * k, [p + 1] * k, np.repeat(corr[p, p + 1], k),
+                                np.arange(k + 1, dtype=np.int64) * p, np.tile(cand1, k), thr)
+    assert np.all(many[1] == one[1][0]) and np.all(many[2] == one[2][0])
+    assert np.array_equal(many[0].reshape(k, p), np.tile(one[0], (k, 1)))
+
+
 def test_bad_arguments_are_refused():
     import cigwas_amd as cg
 
