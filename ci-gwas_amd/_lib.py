@@ -35,6 +35,24 @@ class CuskStats(C.Structure):
     ]
 
 
+class CuskBlockStats(C.Structure):
+    """cusk_block_stats of include/cusk_hip.h"""
+    _fields_ = [
+        ("skipped", C.c_int),
+        ("num_sig", C.c_int),
+        ("markers", C.c_longlong),
+        ("retained", C.c_longlong),
+        ("tests", C.c_longlong * 2),
+        ("ms_inputs", C.c_double),
+        ("ms_corr", C.c_double),
+        ("ms_stage1", C.c_double),
+        ("ms_prune", C.c_double),
+        ("ms_stage2", C.c_double),
+        ("ms_reduce", C.c_double),
+        ("stage", CuskStats * 2),
+    ]
+
+
 # every symbol include/cusk_hip.h declares: (restype, argtypes)
 _vp, _i, _f, _sz, _ll = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_longlong
 SYMBOLS = {
@@ -49,6 +67,7 @@ SYMBOLS = {
     "cusk_last_error": (C.c_char_p, [_vp]),
     "cusk_engine_set_option": (_i, [_vp, C.c_char_p, _ll]),
     "cusk_engine_stream": (_vp, [_vp]),
+    "cusk_engine_bind_thread": (_i, [_vp]),
     "cusk_engine_set_row_shard": (_i, [_vp, _i, _i, _vp, _vp, _i]),
     "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
@@ -66,6 +85,23 @@ SYMBOLS = {
     "cusk_hanning_smooth": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
     "cusk_sepselect_greedy": (_i, [_vp, _vp, C.c_longlong, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cusk_gather_submatrix": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "cusk_blockset_open": (_i, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_char_p, _f, _i, _i, _i, C.c_char_p, _sz]),
+    "cusk_blockset_close": (None, [_vp]),
+    "cusk_blockset_num_blocks": (_i, [_vp]),
+    "cusk_blockset_num_samples": (_ll, [_vp]),
+    "cusk_blockset_num_phen": (_i, [_vp]),
+    "cusk_blockset_block_markers": (_ll, [_vp, _i]),
+    "cusk_blockset_block_stem": (_i, [_vp, _i, C.c_char_p, _sz]),
+    "cusk_blockset_run_block": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
+    "cusk_blockset_last_error": (C.c_char_p, []),
+    "cusk_block_result_dims": (None, [_vp, C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
+    "cusk_block_result_stem": (C.c_char_p, [_vp]),
+    "cusk_block_result_ixs": (_vp, [_vp]),
+    "cusk_block_result_adj": (_vp, [_vp]),
+    "cusk_block_result_corr": (_vp, [_vp]),
+    "cusk_block_result_sep": (_vp, [_vp]),
+    "cusk_block_result_write": (_i, [_vp, C.c_char_p]),
+    "cusk_block_result_free": (None, [_vp]),
     "cusk_dev_alloc": (_vp, [_sz]),
     "cusk_dev_free": (None, [_vp]),
     "cusk_dev_upload": (_i, [_vp, _vp, _sz]),

@@ -683,6 +683,12 @@ extern "C" int cusk_engine_set_row_shard(cusk_engine *e, int rank, int world, cu
 
 extern "C" const char *cusk_last_error(const cusk_engine *e) { return e ? e->err.c_str() : "no engine"; }
 extern "C" void *cusk_engine_stream(const cusk_engine *e) { return e ? (void *)e->stream : nullptr; }
+extern "C" int cusk_engine_bind_thread(cusk_engine *e)
+{
+    if (!e) return CUSK_ERR_ARG;
+    CUSK_HIP(e, hipSetDevice(e->device));
+    return CUSK_OK;
+}
 
 extern "C" int cusk_run_skeleton(cusk_engine *e, const float *C_dev, int n, const float *Th, int maxlevel,
                                  cusk_stats *stats)

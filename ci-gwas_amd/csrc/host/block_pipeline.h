@@ -1,0 +1,440 @@
+// block_pipeline.h -- one LD block through the `cusk` pipeline, shared by the `mps cusk` command (one block per
+// process, /root/reference/cusk/src/cli.cpp:432-678) and by the multi-GPU block driver (many blocks per process:
+// include/cusk_hip.h section 3, ci-gwas_amd/run_blocks.py).  Both callers run exactly this code, so the files of a
+// sharded whole-chromosome run are byte-identical to those of per-block `mps cusk` invocations by construction.
+//
+// Host code against the C ABI only (no HIP headers): correlation build and both skeleton stages run on the engine's
+// device, the matrix never leaves HBM between them, adjacency comes back as a bitmap, separating sets as sparse
+// records, only the retained sub-matrix is gathered to the host.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <numeric>
+#include <stdexcept>
+
+#include "../../../include/cusk_hip.h"
+#include "host_io.h"
+
+namespace host {
+
+constexpr int ML = CUSK_ML;
+
+// a failed engine call: the CLI prints the message and exits with EXIT_FAILURE (gpuerrors.h:6-15), the library
+// entry points return CUSK_ERR_* with the message retrievable
+struct EngineError : std::runtime_error
+{
+    using std::runtime_error::runtime_error;
+};
+
+[[noreturn]] inline void engine_die(const char *what, cusk_engine *e)
+{
+    throw EngineError(std::string(what) + ": " + (e ? cusk_last_error(e) : "no engine"));
+}
+
+struct Bits
+{
+    int n = 0, words = 0;
+    std::vector<uint64_t> w;
+    bool get(int i, int j) const { return (w[(size_t)i * words + (j >> 6)] >> (j & 63)) & 1ull; }
+};
+
+inline Bits fetch_adjacency(cusk_engine *e)
+{
+    Bits b;
+    b.n = cusk_result_n(e);
+    b.words = cusk_result_words(e);
+    b.w.resize((size_t)b.n * b.words);
+    if (cusk_dev_download(b.w.data(), cusk_result_adj_bits_dev(e), b.w.size() * sizeof(uint64_t)) != CUSK_OK)
+        engine_die("adjacency download", e);
+    return b;
+}
+
+// parent_set.cpp:8-53: all traits, plus markers reached from a trait through marker nodes in
+// at most max_depth hops.  Sorted ascending.
+inline std::vector<int> subset_variables(const Bits &G, int num_var, int num_markers, int max_depth)
+{
+    std::vector<char> keep(num_var, 0);
+    for (int i = num_markers; i < num_var; i++) keep[i] = 1;
+    for (int start = num_markers; start < num_var; start++)
+    {
+        std::vector<char> seen(num_var, 0);
+        for (int i = num_markers; i < num_var; i++) seen[i] = 1;
+        std::vector<int> q{start}, nq;
+        for (int depth = 0; depth < max_depth; depth++)
+        {
+            nq.clear();
+            for (int node : q)
+            {
+                const uint64_t *row = &G.w[(size_t)node * G.words];
+                for (int wv = 0; wv * 64 < num_markers; wv++)
+                {
+                    uint64_t bits = row[wv];
+                    while (bits)
+                    {
+                        const int c = wv * 64 + __builtin_ctzll(bits);
+                        bits &= bits - 1;
+                        if (c < num_markers && !seen[c])
+                        {
+                            seen[c] = 1;
+                            nq.push_back(c);
+                        }
+                    }
+                }
+            }
+            q.swap(nq);
+        }
+        for (int i = 0; i < num_var; i++)
+            if (seen[i]) keep[i] = 1;
+    }
+    std::vector<int> out;
+    for (int i = 0; i < num_var; i++)
+        if (keep[i]) out.push_back(i);
+    return out;
+}
+
+// ReducedGC / ReducedGCS of include/mps/parent_set.h
+struct Reduced
+{
+    size_t num_var = 0, num_phen = 0, max_level = 0;
+    std::vector<int> new_to_old;
+    std::vector<int> G;
+    std::vector<float> C;
+    std::vector<float> ess;  // cuskss
+    std::vector<int> S;      // cusk: num_var^2 * max_level
+    size_t num_markers() const { return num_var - num_phen; }
+};
+
+inline void write_reduced(const Reduced &r, const std::string &base, bool with_sep)
+{
+    {
+        std::ofstream f(base + ".mdim");
+        f << r.num_var << "\t" << r.num_phen << "\t" << r.max_level << std::endl;
+    }
+    write_binary(base + ".ixs", r.new_to_old.data(), r.new_to_old.size());
+    write_binary(base + ".adj", r.G.data(), r.G.size());
+    write_binary(base + ".corr", r.C.data(), r.C.size());
+    if (with_sep) write_binary(base + ".sep", r.S.data(), r.S.size());
+}
+
+inline std::vector<float> gather(cusk_engine *e, const float *M_dev, int n, const std::vector<int> &P)
+{
+    std::vector<float> out(P.size() * P.size());
+    if (cusk_gather_submatrix(e, M_dev, n, P.data(), (int)P.size(), out.data()) != CUSK_OK) engine_die("gather", e);
+    return out;
+}
+
+inline std::vector<int> gather_adj(const Bits &G, const std::vector<int> &P)
+{
+    std::vector<int> out(P.size() * P.size());
+    for (size_t a = 0; a < P.size(); a++)
+        for (size_t b = 0; b < P.size(); b++) out[a * P.size() + b] = G.get(P[a], P[b]) ? 1 : 0;
+    return out;
+}
+
+// parent_set.cpp:84-175 on sparse records.  Entries of a set that are not retained are dropped, the
+// rest is compacted and padded with -1 to `max_level`; at most `max_level` source entries are read.
+// With an index_map (stage two) the reference keys old_to_new by index_map[P[i]] although the set
+// members are still in the P index space: a member that is not a key maps to 0.
+inline std::vector<int> reduce_sepsets(cusk_engine *e, const std::vector<int> &P, size_t max_level,
+                                       const std::vector<int> *index_map)
+{
+    const size_t k = P.size();
+    std::vector<int> S(k * k * max_level, -1);
+    const long long cnt = cusk_result_sepsets(e, nullptr, nullptr, nullptr, nullptr, nullptr);
+    if (cnt < 0) engine_die("sepsets", e);
+    if (cnt == 0) return S;
+    std::vector<int> x(cnt), y(cnt), rs((size_t)cnt * ML);
+    if (cusk_result_sepsets(e, x.data(), y.data(), nullptr, nullptr, rs.data()) != cnt) engine_die("sepsets", e);
+    std::unordered_map<int, int> pos, old_to_new;
+    for (size_t i = 0; i < k; i++)
+    {
+        pos[P[i]] = (int)i;
+        old_to_new[index_map ? (*index_map)[P[i]] : P[i]] = (int)i;
+    }
+    for (long long r = 0; r < cnt; r++)
+    {
+        auto ix = pos.find(x[r]), iy = pos.find(y[r]);
+        if (ix == pos.end() || iy == pos.end()) continue;
+        int *dst = &S[((size_t)ix->second * k + iy->second) * max_level];
+        size_t c = 0;
+        for (size_t l = 0; l < max_level && l < (size_t)ML; l++)
+        {
+            const int sv = rs[(size_t)r * ML + l];
+            if (sv != -1 && pos.count(sv))
+            {
+                auto it = old_to_new.find(sv);
+                dst[c++] = (it == old_to_new.end()) ? 0 : it->second;
+            }
+        }
+    }
+    return S;
+}
+
+inline std::vector<int> compose(const std::vector<int> &P, const std::vector<int> *index_map)
+{
+    std::vector<int> out(P.size());
+    for (size_t i = 0; i < P.size(); i++) out[i] = index_map ? (*index_map)[P[i]] : P[i];
+    return out;
+}
+
+// device matrix that is reused from block to block (grows, never shrinks)
+struct DevMat
+{
+    float *p = nullptr;
+    size_t cap = 0;
+    DevMat() = default;
+    explicit DevMat(size_t count) { reserve(count); }
+    DevMat(const std::vector<float> &h) { upload(h); }
+    void reserve(size_t count)
+    {
+        if (count <= cap) return;
+        cusk_dev_free(p);
+        p = static_cast<float *>(cusk_dev_alloc(sizeof(float) * count));
+        cap = p ? count : 0;
+        if (!p) throw EngineError("device allocation of " + std::to_string(sizeof(float) * count) + " bytes failed");
+    }
+    void upload(const std::vector<float> &h)
+    {
+        reserve(h.size());
+        if (cusk_dev_upload(p, h.data(), sizeof(float) * h.size()) != CUSK_OK) throw EngineError("device upload failed");
+    }
+    ~DevMat() { cusk_dev_free(p); }
+    DevMat(const DevMat &) = delete;
+    DevMat &operator=(const DevMat &) = delete;
+};
+
+// read-only memory map of the .bed (a whole-genome file is read block by block, by whichever rank owns the block)
+struct MappedFile
+{
+    const unsigned char *data = nullptr;
+    size_t size = 0;
+    int fd = -1;
+    void open(const std::string &path)
+    {
+        close();
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) die("file or directory not found: " + path);
+        struct stat st;
+        if (fstat(fd, &st) != 0) die("cannot stat " + path);
+        size = (size_t)st.st_size;
+        if (size)
+        {
+            void *p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (p == MAP_FAILED) die("cannot map " + path);
+            data = static_cast<const unsigned char *>(p);
+        }
+    }
+    void close()
+    {
+        if (data) munmap(const_cast<unsigned char *>(data), size);
+        if (fd >= 0) ::close(fd);
+        data = nullptr;
+        size = 0;
+        fd = -1;
+    }
+    ~MappedFile() { close(); }
+    MappedFile() = default;
+    MappedFile(const MappedFile &) = delete;
+    MappedFile &operator=(const MappedFile &) = delete;
+};
+
+// what `mps cusk` loads before it turns to its block (cli.cpp:458-497); loaded once, shared by all blocks
+struct CuskInputs
+{
+    std::string phen_path, bfiles, block_path;
+    float alpha = 0.0f;
+    int max_level = 0, max_level_two = 0, depth = 1;
+    std::string full_corrmats_dir;  // not empty: also write <stem>.all_corrs there (cli.cpp:651-658)
+    Phen phen;
+    BedDims dims;
+    BimInfo bim;
+    std::vector<Block> blocks;
+    float Th[ML + 1];
+    MappedFile bed;
+    // all markers' means / stds, read once when several blocks are run from one process (empty: line-range reads)
+    std::vector<float> means_all, stds_all;
+
+    // cli.cpp:458-497 (path checks, .phen, .dim, .bim, .blocks with the bounds check, thresholds)
+    void load(std::ostream *log)
+    {
+        if (log) *log << "Checking paths" << std::endl;
+        for (const char *sfx : {".bed", ".dim", ".means", ".stds", ".bim"}) check_path(bfiles + sfx);
+        if (!bed_has_valid_magic(bfiles + ".bed")) die("unexpected magic number in bed file.");
+        check_path(phen_path);
+        check_path(block_path);
+        phen = load_phen(phen_path);
+        dims = read_dims(bfiles + ".dim");
+        if (phen.num_samples != dims.num_samples) die("different num samples in phen and dims");
+        bim = read_bim(bfiles + ".bim");
+        if (log) *log << "Found " << phen.num_phen << " phenotypes" << std::endl;
+        if (log) *log << "Loading blocks" << std::endl;
+        blocks = read_blocks(block_path);
+        if (log) *log << "Found " << blocks.size() << " blocks" << std::endl;
+        for (const Block &b : blocks)
+            if (b.first >= bim.markers_on(b.chr) || b.last >= bim.markers_on(b.chr))
+                die("block out of bounds with first_ix: " + std::to_string(b.first) + " last_ix: " + std::to_string(b.last));
+        cusk_threshold_array((int)dims.num_samples, alpha, Th);
+        bed.open(bfiles + ".bed");
+    }
+    void load_all_marker_stats()
+    {
+        means_all = read_floats_line_range(bfiles + ".means", 0, std::numeric_limits<size_t>::max());
+        stds_all = read_floats_line_range(bfiles + ".stds", 0, std::numeric_limits<size_t>::max());
+    }
+    size_t first_marker(const Block &b) const { return bim.start_of(b.chr) + b.first; }
+};
+
+struct BlockStats
+{
+    int skipped = 0;         // cli.cpp:572-576: no marginally significant marker-trait correlation, no output
+    int num_sig = 0;
+    long long markers = 0;   // block size
+    long long retained = 0;  // markers in the written result
+    long long tests[2] = {0, 0};  // CI tests of stage one / stage two (SURVEY.md 8d definition)
+    cusk_stats stage[2];
+    // wall-clock phases, ms: inputs (bed slice, means, stds), correlation build, stage one, prune + gather,
+    // stage two, reduction
+    double ms_inputs = 0, ms_corr = 0, ms_stage1 = 0, ms_prune = 0, ms_stage2 = 0, ms_reduce = 0;
+};
+
+// per-caller device scratch that survives from block to block
+struct BlockScratch
+{
+    DevMat C, C2;
+};
+
+// cli.cpp:521-677 for blocks[block_index] on the engine's device.  Returns false when the block is skipped.
+inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index, BlockScratch &scr, Reduced &out,
+                           std::string &stem, BlockStats &bs, std::ostream *log)
+{
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point &t) {
+        const auto now = clk::now();
+        const double v = std::chrono::duration<double, std::milli>(now - t).count();
+        t = now;
+        return v;
+    };
+    if (block_index < 0 || (size_t)block_index >= in.blocks.size()) die("block index out of range");
+    if (cusk_engine_bind_thread(e) != CUSK_OK) engine_die("bind thread", e);  // the scratch matrices go to e's device
+    const Block &block = in.blocks[block_index];
+    stem = block.file_stem();
+    const size_t m = block.size(), N = in.dims.num_samples, p = in.phen.num_phen;
+    bs = BlockStats();
+    bs.markers = (long long)m;
+    auto t = clk::now();
+    if (log)
+    {
+        *log << "\nProcessing block " << block_index + 1 << " / " << in.blocks.size() << std::endl;
+        *log << "Block size: " << m << std::endl;
+        *log << "Loading bed data" << std::endl;
+    }
+    const size_t g0 = in.first_marker(block), g1 = g0 + m - 1;
+    const size_t bpc = in.dims.bytes_per_col();
+    if (3 + (g1 + 1) * bpc > in.bed.size) die("bed file is shorter than .dim / .bim say");
+    const unsigned char *bed = in.bed.data + 3 + g0 * bpc;  // io.cpp:238-249
+    std::vector<float> means_v, stds_v;
+    const float *means, *stds;
+    if (!in.means_all.empty())
+    {
+        if (g1 >= in.means_all.size() || g1 >= in.stds_all.size()) die("block size and number of means or stds differ");
+        means = in.means_all.data() + g0;
+        stds = in.stds_all.data() + g0;
+    }
+    else
+    {
+        means_v = read_floats_line_range(in.bfiles + ".means", g0, g1);
+        stds_v = read_floats_line_range(in.bfiles + ".stds", g0, g1);
+        if (means_v.size() != m || stds_v.size() != m) die("block size and number of means or stds differ");
+        means = means_v.data();
+        stds = stds_v.data();
+    }
+    bs.ms_inputs = ms_since(t);
+
+    const size_t n = m + p;
+    scr.C.reserve(n * n);
+    if (log)
+    {
+        *log << "Checking for significant marker - phen correlations" << std::endl;
+        *log << "Computing all correlations" << std::endl;
+    }
+    std::vector<float> mxp(m * p);
+    if (cusk_corr_build(e, bed, in.phen.data.data(), m, N, p, means, stds, scr.C.p, mxp.data()) != CUSK_OK)
+        engine_die("correlation build", e);
+    bs.ms_corr = ms_since(t);
+    // cli.cpp:561-576: blocks without any marginally significant marker-trait correlation are skipped
+    int num_sig = 0;
+    for (float c : mxp) num_sig += (std::fabs(0.5 * (std::log(std::fabs((1 + c))) - std::log(std::fabs(1 - c)))) >= in.Th[0]);
+    bs.num_sig = num_sig;
+    if (num_sig > 0)
+    {
+        if (log) *log << "Found " << num_sig << " marker - phen correlations. Proceeding." << std::endl;
+    }
+    else
+    {
+        if (log) *log << "No significant correlations found. Skipping block." << std::endl;
+        bs.skipped = 1;
+        return false;
+    }
+    if (!in.full_corrmats_dir.empty())
+    {  // cli.cpp:27,651-658 (compile-time switch WRITE_FULL_CORRMATS in the reference)
+        std::vector<float> full(n * n);
+        cusk_dev_download(full.data(), scr.C.p, sizeof(float) * n * n);
+        write_binary(make_path(in.full_corrmats_dir, stem, ".all_corrs"), full.data(), full.size());
+    }
+
+    if (log) *log << "Running cuPC" << std::endl;
+    cusk_engine_set_option(e, "assume_symmetric", 1);  // cusk_corr_build mirrors every element
+    cusk_stats &st = bs.stage[0];
+    if (cusk_run_skeleton(e, scr.C.p, (int)n, in.Th, in.max_level, &st) != CUSK_OK) engine_die("Skeleton", e);
+    bs.ms_stage1 = ms_since(t);
+    for (int l = 0; l < st.levels_run; l++)
+    {
+        bs.tests[0] += st.tests[l];
+        if (log)
+            *log << "level " << l << ": max degree " << st.max_degree[l] << ", " << st.tests[l] << " tests, "
+                 << st.level_ms[l] * 1e-3 << " s" << std::endl;
+    }
+    Bits G = fetch_adjacency(e);
+    std::vector<int> P = subset_variables(G, (int)n, (int)m, in.depth);
+    Reduced gcs;
+    gcs.num_var = P.size();
+    gcs.num_phen = p;
+    gcs.max_level = (size_t)in.max_level;
+    gcs.new_to_old = P;
+    gcs.C = gather(e, scr.C.p, (int)n, P);
+    bs.ms_prune = ms_since(t);
+    // (the stage-one separating sets of cli.cpp:673 are never read again: stage two recomputes them)
+
+    if (log) *log << "Starting second cusk stage" << std::endl;
+    // cli.cpp:62-87: Skeleton again on the reduced set, starting from the complete graph
+    const int k = (int)gcs.num_var;
+    scr.C2.upload(gcs.C);
+    cusk_engine_set_option(e, "assume_symmetric", 0);
+    cusk_stats &st2 = bs.stage[1];
+    if (cusk_run_skeleton(e, scr.C2.p, k, in.Th, in.max_level_two, &st2) != CUSK_OK) engine_die("Skeleton (stage two)", e);
+    bs.ms_stage2 = ms_since(t);
+    for (int l = 0; l < st2.levels_run; l++) bs.tests[1] += st2.tests[l];
+    Bits G2 = fetch_adjacency(e);
+    std::vector<int> P2 = subset_variables(G2, k, (int)gcs.num_markers(), in.depth);
+    out = Reduced();
+    out.num_var = P2.size();
+    out.num_phen = p;
+    out.max_level = ML;
+    out.new_to_old = compose(P2, &gcs.new_to_old);
+    out.G = gather_adj(G2, P2);
+    out.C = gather(e, scr.C2.p, k, P2);
+    out.S = reduce_sepsets(e, P2, ML, &gcs.new_to_old);
+    bs.retained = (long long)out.num_markers();
+    if (log) *log << "Retained " << out.num_markers() << " markers" << std::endl;
+    bs.ms_reduce = ms_since(t);
+    return true;
+}
+
+}  // namespace host

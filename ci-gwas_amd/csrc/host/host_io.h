@@ -14,17 +14,21 @@
 #include <iostream>
 #include <limits>
 #include <sstream>
+#include <stdexcept>
 #include <string>
 #include <unordered_map>
 #include <vector>
 
 namespace host {
 
-[[noreturn]] inline void die(const std::string &msg)
+// Bad input ends the reference's program with a message and status 1 (cli.cpp:185-192, io.cpp:399-406).  Here it is
+// an exception so that the same loaders serve the library entry points: `mps` catches it in main() and does exactly
+// that, the cusk_blockset_* calls turn it into an error code.
+struct Fatal : std::runtime_error
 {
-    std::cerr << msg << std::endl;
-    std::exit(1);
-}
+    using std::runtime_error::runtime_error;
+};
+[[noreturn]] inline void die(const std::string &msg) { throw Fatal(msg); }
 
 inline bool path_exists(const std::string &p)
 {

@@ -18,182 +18,13 @@
 #include <set>
 
 #include "../../../include/cusk_hip.h"
+#include "block_pipeline.h"
 #include "blocking.h"
 #include "host_io.h"
 
 using namespace host;
 
 namespace {
-
-constexpr int ML = CUSK_ML;
-
-[[noreturn]] void engine_die(const char *what, cusk_engine *e)
-{
-    std::fprintf(stderr, "mps: %s: %s\n", what, e ? cusk_last_error(e) : "no engine");
-    std::exit(EXIT_FAILURE);
-}
-
-struct Bits
-{
-    int n = 0, words = 0;
-    std::vector<uint64_t> w;
-    bool get(int i, int j) const { return (w[(size_t)i * words + (j >> 6)] >> (j & 63)) & 1ull; }
-};
-
-Bits fetch_adjacency(cusk_engine *e)
-{
-    Bits b;
-    b.n = cusk_result_n(e);
-    b.words = cusk_result_words(e);
-    b.w.resize((size_t)b.n * b.words);
-    if (cusk_dev_download(b.w.data(), cusk_result_adj_bits_dev(e), b.w.size() * sizeof(uint64_t)) != CUSK_OK)
-        engine_die("adjacency download", e);
-    return b;
-}
-
-// parent_set.cpp:8-53: all traits, plus markers reached from a trait through marker nodes in
-// at most max_depth hops.  Sorted ascending.
-std::vector<int> subset_variables(const Bits &G, int num_var, int num_markers, int max_depth)
-{
-    std::vector<char> keep(num_var, 0);
-    for (int i = num_markers; i < num_var; i++) keep[i] = 1;
-    for (int start = num_markers; start < num_var; start++)
-    {
-        std::vector<char> seen(num_var, 0);
-        for (int i = num_markers; i < num_var; i++) seen[i] = 1;
-        std::vector<int> q{start}, nq;
-        for (int depth = 0; depth < max_depth; depth++)
-        {
-            nq.clear();
-            for (int node : q)
-            {
-                const uint64_t *row = &G.w[(size_t)node * G.words];
-                for (int wv = 0; wv * 64 < num_markers; wv++)
-                {
-                    uint64_t bits = row[wv];
-                    while (bits)
-                    {
-                        const int c = wv * 64 + __builtin_ctzll(bits);
-                        bits &= bits - 1;
-                        if (c < num_markers && !seen[c])
-                        {
-                            seen[c] = 1;
-                            nq.push_back(c);
-                        }
-                    }
-                }
-            }
-            q.swap(nq);
-        }
-        for (int i = 0; i < num_var; i++)
-            if (seen[i]) keep[i] = 1;
-    }
-    std::vector<int> out;
-    for (int i = 0; i < num_var; i++)
-        if (keep[i]) out.push_back(i);
-    return out;
-}
-
-// ReducedGC / ReducedGCS of include/mps/parent_set.h
-struct Reduced
-{
-    size_t num_var = 0, num_phen = 0, max_level = 0;
-    std::vector<int> new_to_old;
-    std::vector<int> G;
-    std::vector<float> C;
-    std::vector<float> ess;  // cuskss
-    std::vector<int> S;      // cusk: num_var^2 * max_level
-    size_t num_markers() const { return num_var - num_phen; }
-};
-
-void write_reduced(const Reduced &r, const std::string &base, bool with_sep)
-{
-    {
-        std::ofstream f(base + ".mdim");
-        f << r.num_var << "\t" << r.num_phen << "\t" << r.max_level << std::endl;
-    }
-    write_binary(base + ".ixs", r.new_to_old.data(), r.new_to_old.size());
-    write_binary(base + ".adj", r.G.data(), r.G.size());
-    write_binary(base + ".corr", r.C.data(), r.C.size());
-    if (with_sep) write_binary(base + ".sep", r.S.data(), r.S.size());
-}
-
-std::vector<float> gather(cusk_engine *e, const float *M_dev, int n, const std::vector<int> &P)
-{
-    std::vector<float> out(P.size() * P.size());
-    if (cusk_gather_submatrix(e, M_dev, n, P.data(), (int)P.size(), out.data()) != CUSK_OK) engine_die("gather", e);
-    return out;
-}
-
-std::vector<int> gather_adj(const Bits &G, const std::vector<int> &P)
-{
-    std::vector<int> out(P.size() * P.size());
-    for (size_t a = 0; a < P.size(); a++)
-        for (size_t b = 0; b < P.size(); b++) out[a * P.size() + b] = G.get(P[a], P[b]) ? 1 : 0;
-    return out;
-}
-
-// parent_set.cpp:84-175 on sparse records.  Entries of a set that are not retained are dropped, the
-// rest is compacted and padded with -1 to `max_level`; at most `max_level` source entries are read.
-// With an index_map (stage two) the reference keys old_to_new by index_map[P[i]] although the set
-// members are still in the P index space: a member that is not a key maps to 0.
-std::vector<int> reduce_sepsets(cusk_engine *e, const std::vector<int> &P, size_t max_level, const std::vector<int> *index_map)
-{
-    const size_t k = P.size();
-    std::vector<int> S(k * k * max_level, -1);
-    const long long cnt = cusk_result_sepsets(e, nullptr, nullptr, nullptr, nullptr, nullptr);
-    if (cnt < 0) engine_die("sepsets", e);
-    if (cnt == 0) return S;
-    std::vector<int> x(cnt), y(cnt), rs((size_t)cnt * ML);
-    if (cusk_result_sepsets(e, x.data(), y.data(), nullptr, nullptr, rs.data()) != cnt) engine_die("sepsets", e);
-    std::unordered_map<int, int> pos, old_to_new;
-    for (size_t i = 0; i < k; i++)
-    {
-        pos[P[i]] = (int)i;
-        old_to_new[index_map ? (*index_map)[P[i]] : P[i]] = (int)i;
-    }
-    for (long long r = 0; r < cnt; r++)
-    {
-        auto ix = pos.find(x[r]), iy = pos.find(y[r]);
-        if (ix == pos.end() || iy == pos.end()) continue;
-        int *dst = &S[((size_t)ix->second * k + iy->second) * max_level];
-        size_t c = 0;
-        for (size_t l = 0; l < max_level && l < (size_t)ML; l++)
-        {
-            const int sv = rs[(size_t)r * ML + l];
-            if (sv != -1 && pos.count(sv))
-            {
-                auto it = old_to_new.find(sv);
-                dst[c++] = (it == old_to_new.end()) ? 0 : it->second;
-            }
-        }
-    }
-    return S;
-}
-
-std::vector<int> compose(const std::vector<int> &P, const std::vector<int> *index_map)
-{
-    std::vector<int> out(P.size());
-    for (size_t i = 0; i < P.size(); i++) out[i] = index_map ? (*index_map)[P[i]] : P[i];
-    return out;
-}
-
-struct DevMat
-{
-    float *p = nullptr;
-    explicit DevMat(size_t count) { p = static_cast<float *>(cusk_dev_alloc(sizeof(float) * count)); }
-    DevMat(const std::vector<float> &h) : DevMat(h.size())
-    {
-        if (!p || cusk_dev_upload(p, h.data(), sizeof(float) * h.size()) != CUSK_OK)
-        {
-            std::fprintf(stderr, "mps: device upload failed\n");
-            std::exit(EXIT_FAILURE);
-        }
-    }
-    ~DevMat() { cusk_dev_free(p); }
-    DevMat(const DevMat &) = delete;
-    DevMat &operator=(const DevMat &) = delete;
-};
 
 // ---------------------------------------------------------------------------------------
 // mps cusk   (cli.cpp:432-678)
@@ -226,133 +57,59 @@ int cmd_cusk(int argc, char **argv)
         std::cout << CUSK_USAGE << std::endl;
         std::exit(1);
     }
-    const std::string phen_path = argv[2], bfiles = argv[3], block_path = argv[4];
-    const float alpha = std::stof(argv[5]);
-    int max_level = std::stoi(argv[6]);
-    int max_level_two = std::stoi(argv[7]);
-    const int depth = std::stoi(argv[8]);
+    CuskInputs in;
+    in.phen_path = argv[2];
+    in.bfiles = argv[3];
+    in.block_path = argv[4];
+    in.alpha = std::stof(argv[5]);
+    in.max_level = std::stoi(argv[6]);
+    in.max_level_two = std::stoi(argv[7]);
+    in.depth = std::stoi(argv[8]);
     const std::string outdir = argv[9];
     const int block_index = std::stoi(argv[10]);
-    std::cout << "Got args: \n.phen: " << phen_path << "\nbfiles: " << bfiles << "\n.blocks: " << block_path
-              << "\nalpha: " << alpha << "\nmax_level: " << max_level << "\nmax_level_two: " << max_level_two
-              << "\ndepth: " << depth << "\noutdir: " << outdir << "\nblock-index: " << block_index << std::endl;
+    std::cout << "Got args: \n.phen: " << in.phen_path << "\nbfiles: " << in.bfiles << "\n.blocks: " << in.block_path
+              << "\nalpha: " << in.alpha << "\nmax_level: " << in.max_level << "\nmax_level_two: " << in.max_level_two
+              << "\ndepth: " << in.depth << "\noutdir: " << outdir << "\nblock-index: " << block_index << std::endl;
 
     PhaseTimer tm;
-    std::cout << "Checking paths" << std::endl;
-    for (const char *sfx : {".bed", ".dim", ".means", ".stds", ".bim"}) check_path(bfiles + sfx);
-    if (!bed_has_valid_magic(bfiles + ".bed")) die("unexpected magic number in bed file.");
-    check_path(phen_path);
-    check_path(block_path);
     check_path(outdir);
-
-    Phen phen = load_phen(phen_path);
-    tm.mark("load phen");
-    const BedDims dims = read_dims(bfiles + ".dim");
-    if (phen.num_samples != dims.num_samples) die("different num samples in phen and dims");
-    const BimInfo bim = read_bim(bfiles + ".bim");
-    const size_t N = dims.num_samples, p = phen.num_phen;
-    std::cout << "Found " << p << " phenotypes" << std::endl;
-    std::cout << "Loading blocks" << std::endl;
-    const std::vector<Block> blocks = read_blocks(block_path);
-    std::cout << "Found " << blocks.size() << " blocks" << std::endl;
-    for (const Block &b : blocks)
-        if (b.first >= bim.markers_on(b.chr) || b.last >= bim.markers_on(b.chr))
-            die("block out of bounds with first_ix: " + std::to_string(b.first) + " last_ix: " + std::to_string(b.last));
-    if (block_index < 0 || (size_t)block_index >= blocks.size()) die("block index out of range");
-
-    float Th[ML + 1];
-    cusk_threshold_array((int)N, alpha, Th);
-    std::cout << "Number of levels: " << max_level << std::endl;
+    in.load(&std::cout);  // cli.cpp:458-497
+    tm.mark("load phen, dim, bim, blocks; map bed");
+    if (block_index < 0 || (size_t)block_index >= in.blocks.size()) die("block index out of range");
+    std::cout << "Number of levels: " << in.max_level << std::endl;
     std::cout << "Setting level thr for cuPC: " << std::endl;
-    for (int i = 0; i <= std::min(max_level, ML); ++i) std::cout << "\t Level: " << i << " thr: " << Th[i] << std::endl;
-
-    const Block block = blocks[block_index];
-    const size_t m = block.size();
-    std::cout << "\nProcessing block " << block_index + 1 << " / " << blocks.size() << std::endl;
-    std::cout << "Block size: " << m << std::endl;
-    std::cout << "Loading bed data" << std::endl;
-    const std::vector<unsigned char> bed = read_bed_block(bfiles + ".bed", block, dims, bim);
-    const size_t g0 = bim.start_of(block.chr) + block.first, g1 = bim.start_of(block.chr) + block.last;
-    const std::vector<float> means = read_floats_line_range(bfiles + ".means", g0, g1);
-    const std::vector<float> stds = read_floats_line_range(bfiles + ".stds", g0, g1);
-    if (means.size() != m || stds.size() != m) die("block size and number of means or stds differ");
-    tm.mark("bim, blocks, bed block, means, stds");
+    for (int i = 0; i <= std::min(in.max_level, ML); ++i) std::cout << "\t Level: " << i << " thr: " << in.Th[i] << std::endl;
+    if (std::getenv("CUSK_WRITE_FULL_CORRMATS")) in.full_corrmats_dir = outdir;
 
     cusk_engine *e = nullptr;
     if (cusk_engine_create(&e, 0, nullptr) != CUSK_OK) engine_die("engine create (is a HIP device visible?)", nullptr);
-    const size_t n = m + p;
-    DevMat C(n * n);
-    if (!C.p) engine_die("device allocation", e);
-    tm.mark("engine create + device allocation");
-
-    std::cout << "Checking for significant marker - phen correlations" << std::endl;
-    std::cout << "Computing all correlations" << std::endl;
-    std::vector<float> mxp(m * p);
-    if (cusk_corr_build(e, bed.data(), phen.data.data(), m, N, p, means.data(), stds.data(), C.p, mxp.data()) != CUSK_OK)
-        engine_die("correlation build", e);
-    tm.mark("correlation build (H2D + kernels + mxp D2H)");
-    // cli.cpp:561-576: blocks without any marginally significant marker-trait correlation are skipped
-    int num_sig = 0;
-    for (float c : mxp) num_sig += (std::fabs(0.5 * (std::log(std::fabs((1 + c))) - std::log(std::fabs(1 - c)))) >= Th[0]);
-    if (num_sig > 0)
-        std::cout << "Found " << num_sig << " marker - phen correlations. Proceeding." << std::endl;
-    else
+    tm.mark("engine create");
+    // the one block of this invocation through the pipeline the block driver runs for every block of a chromosome
+    BlockScratch scratch;
+    Reduced out;
+    std::string stem;
+    BlockStats bs;
+    const bool kept = run_cusk_block(e, in, block_index, scratch, out, stem, bs, &std::cout);
+    if (tm.on)
     {
-        std::cout << "No significant correlations found. Skipping block." << std::endl;
-        cusk_engine_destroy(e);
-        return 0;
-    }
-    if (std::getenv("CUSK_WRITE_FULL_CORRMATS"))
-    {  // cli.cpp:27,651-658 (compile-time switch in the reference)
-        std::vector<float> full(n * n);
-        cusk_dev_download(full.data(), C.p, sizeof(float) * n * n);
-        write_binary(make_path(outdir, block.file_stem(), ".all_corrs"), full.data(), full.size());
-    }
-
-    std::cout << "Running cuPC" << std::endl;
-    cusk_engine_set_option(e, "assume_symmetric", 1);  // cusk_corr_build mirrors every element
-    cusk_stats st;
-    if (cusk_run_skeleton(e, C.p, (int)n, Th, max_level, &st) != CUSK_OK) engine_die("Skeleton", e);
-    tm.mark("skeleton stage one");
-    for (int l = 0; l < st.levels_run; l++)
-        std::cout << "level " << l << ": max degree " << st.max_degree[l] << ", " << st.tests[l] << " tests, "
-                  << st.level_ms[l] * 1e-3 << " s" << std::endl;
-    Bits G = fetch_adjacency(e);
-    std::vector<int> P = subset_variables(G, (int)n, (int)m, depth);
-    Reduced gcs;
-    gcs.num_var = P.size();
-    gcs.num_phen = p;
-    gcs.max_level = (size_t)max_level;
-    gcs.new_to_old = P;
-    gcs.C = gather(e, C.p, (int)n, P);
-    tm.mark("adjacency fetch + prune + sub-matrix gather");
-    // (the stage-one separating sets of cli.cpp:673 are never read again: stage two recomputes them)
-
-    std::cout << "Starting second cusk stage" << std::endl;
-    {  // cli.cpp:62-87: Skeleton again on the reduced set, starting from the complete graph
-        const int k = (int)gcs.num_var;
-        DevMat C2(gcs.C);
-        cusk_engine_set_option(e, "assume_symmetric", 0);
-        if (cusk_run_skeleton(e, C2.p, k, Th, max_level_two, &st) != CUSK_OK) engine_die("Skeleton (stage two)", e);
-        tm.mark("skeleton stage two");
-        if (tm.on)
+        std::cout << "[t] inputs (bed slice, means, stds): " << bs.ms_inputs << " ms\n[t] correlation build (H2D + kernels + mxp D2H): "
+                  << bs.ms_corr << " ms" << std::endl;
+        if (kept)
+        {
+            std::cout << "[t] skeleton stage one: " << bs.ms_stage1 << " ms\n[t] adjacency fetch + prune + sub-matrix gather: "
+                      << bs.ms_prune << " ms\n[t] skeleton stage two: " << bs.ms_stage2 << " ms\n[t] stage-two reduction: "
+                      << bs.ms_reduce << " ms" << std::endl;
+            const cusk_stats &st = bs.stage[1];
             for (int l = 0; l < st.levels_run; l++)
                 std::cout << "[t] stage two level " << l << ": max degree " << st.max_degree[l] << ", " << st.edges[l]
                           << " edges, " << st.tests[l] << " tests, " << st.subsets[l] << " sets, " << st.rechecks[l]
                           << " rechecks, sweep " << st.kernel_ms[l] << " ms, level " << st.level_ms[l] << " ms" << std::endl;
-        Bits G2 = fetch_adjacency(e);
-        std::vector<int> P2 = subset_variables(G2, k, (int)gcs.num_markers(), depth);
-        Reduced out;
-        out.num_var = P2.size();
-        out.num_phen = p;
-        out.max_level = ML;
-        out.new_to_old = compose(P2, &gcs.new_to_old);
-        out.G = gather_adj(G2, P2);
-        out.C = gather(e, C2.p, k, P2);
-        out.S = reduce_sepsets(e, P2, ML, &gcs.new_to_old);
-        std::cout << "Retained " << out.num_markers() << " markers" << std::endl;
-        tm.mark("stage-two reduction");
-        write_reduced(out, make_path(outdir, block.file_stem(), ""), true);
+        }
+        tm.mark("block pipeline");
+    }
+    if (kept)
+    {
+        write_reduced(out, make_path(outdir, stem, ""), true);
         tm.mark("write outputs");
     }
     cusk_engine_destroy(e);
@@ -742,10 +499,23 @@ int main(int argc, char **argv)
         return EXIT_SUCCESS;
     }
     const std::string cmd = argv[1];
-    if (cmd == "cusk") return cmd_cusk(argc, argv);
-    if (cmd == "cuskss") return cmd_cuskss(argc, argv);
-    if (cmd == "block") return cmd_block(argc, argv);
-    if (cmd == "prep") return cmd_prep(argc, argv);
+    try
+    {
+        if (cmd == "cusk") return cmd_cusk(argc, argv);
+        if (cmd == "cuskss") return cmd_cuskss(argc, argv);
+        if (cmd == "block") return cmd_block(argc, argv);
+        if (cmd == "prep") return cmd_prep(argc, argv);
+    }
+    catch (const Fatal &f)
+    {  // bad input: message + status 1, as the reference's loaders and argument checks do (cli.cpp:185-192)
+        std::cerr << f.what() << std::endl;
+        return 1;
+    }
+    catch (const EngineError &f)
+    {  // device failure: gpuerrors.h:6-15
+        std::fprintf(stderr, "mps: %s\n", f.what());
+        return EXIT_FAILURE;
+    }
     std::cout << MPS_USAGE << std::endl;
     return EXIT_SUCCESS;
 }

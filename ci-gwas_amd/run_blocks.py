@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""Multi-GPU block driver: every LD block of a `.blocks` file through the `cusk` pipeline, one process per GPU.
+
+The reference runs one LD block per `mps cusk` invocation and leaves the loop over blocks to the cluster scheduler
+(/root/reference/README.md:62, cusk/src/cli.cpp:507-512).  Here one job does the whole file:
+
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port P \
+        ci-gwas_amd/run_blocks.py <.phen> <bfiles> <.blocks> <alpha> <max-level> <max-level-two> <depth> <outdir>
+
+(the positional arguments of `mps cusk` without the block index).  Every rank opens the block set once
+(`cusk_blockset_open`: .phen, .dim, .bim, .means, .stds, thresholds; the .bed is memory-mapped), takes its share of the
+blocks -- static longest-processing-time assignment on predicted costs (`shard.assign_blocks`), or a shared counter
+in the job's c10d store for `--schedule dynamic` -- and runs each one through `cusk_blockset_run_block`, which is the
+very code `mps cusk` runs for a block (csrc/host/block_pipeline.h): correlation build -> skeleton stage one -> prune
+-> stage two -> reduction, everything on the rank's GPU.  There is no collective in the data path.  The one exchange
+is the gather of the per-block reduced results (a few hundred variables each) to rank 0 (`shard.gather_results`: RCCL
+when the backend is nccl, gloo for CPU rehearsals), which writes `<outdir>/<chr>_<first>_<last>.{mdim,ixs,adj,corr,sep}`
+-- byte-identical to per-block `mps cusk` runs, so `merge-block-outputs` consumes them unchanged
+(cusk_postprocessing/merge_blocks.py:361-395; skipped blocks simply have no files, :371-386).
+
+Small blocks do not fill an MI355X (a 500-SNP block is a chain of launch-latency-bound kernels), so a rank keeps
+`--inflight` blocks going at once: that many engines (own streams, own scratch) on the same GPU, one host thread each.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+if __package__ in (None, ""):  # run as a script (torchrun): make `cigwas_amd` importable
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import cigwas_amd  # noqa: F401
+    from cigwas_amd import shard
+    from cigwas_amd._lib import CuskBlockStats, lib
+    from cigwas_amd.skeleton import Engine
+else:
+    from . import shard
+    from ._lib import CuskBlockStats, lib
+    from .skeleton import Engine
+
+
+class BlockSet:
+    """cusk_blockset_* of include/cusk_hip.h: the inputs of `mps cusk`, opened once for all blocks."""
+
+    def __init__(self, phen: str, bfiles: str, blocks: str, alpha: float, max_level: int, max_level_two: int, depth: int):
+        h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        rc = lib().cusk_blockset_open(C.byref(h), phen.encode(), bfiles.encode(), blocks.encode(), float(np.float32(alpha)),
+                                      int(max_level), int(max_level_two), int(depth), err, len(err))
+        if rc != 0:
+            raise RuntimeError(f"cusk_blockset_open: {err.value.decode()}")
+        self.h = h
+        self.num_blocks = lib().cusk_blockset_num_blocks(h)
+        self.num_samples = int(lib().cusk_blockset_num_samples(h))
+        self.num_phen = lib().cusk_blockset_num_phen(h)
+
+    def close(self):
+        if self.h:
+            lib().cusk_blockset_close(self.h)
+            self.h = None
+
+    def markers(self, i: int) -> int:
+        return int(lib().cusk_blockset_block_markers(self.h, i))
+
+    def stem(self, i: int) -> str:
+        buf = C.create_string_buffer(256)
+        if lib().cusk_blockset_block_stem(self.h, i, buf, len(buf)) != 0:
+            raise IndexError(i)
+        return buf.value.decode()
+
+    def costs(self) -> list[float]:
+        return [shard.predicted_cost(self.markers(i), self.num_samples, self.num_phen) for i in range(self.num_blocks)]
+
+    def run_block(self, eng: Engine, i: int):
+        """-> (shard.BlockResult | None if the block is skipped, CuskBlockStats)"""
+        res = C.c_void_p()
+        st = CuskBlockStats()
+        rc = lib().cusk_blockset_run_block(self.h, eng.h, int(i), C.byref(res), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"block {i}: {lib().cusk_blockset_last_error().decode()}")
+        if not res:
+            return None, st
+        try:
+            nv, nph, ml = C.c_longlong(), C.c_longlong(), C.c_longlong()
+            lib().cusk_block_result_dims(res, C.byref(nv), C.byref(nph), C.byref(ml))
+            k, ml_ = int(nv.value), int(ml.value)
+
+            def arr(ptr, ctype, count, dtype):
+                if count == 0:
+                    return np.zeros(0, dtype)
+                return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(ctype)), shape=(count,)).astype(dtype, copy=True)
+
+            br = shard.BlockResult(
+                int(i), lib().cusk_block_result_stem(res).decode(), int(nph.value), ml_,
+                arr(lib().cusk_block_result_ixs(res), C.c_int32, k, np.int32),
+                arr(lib().cusk_block_result_adj(res), C.c_int32, k * k, np.int32).reshape(k, k),
+                arr(lib().cusk_block_result_corr(res), C.c_float, k * k, np.float32).reshape(k, k),
+                arr(lib().cusk_block_result_sep(res), C.c_int32, k * k * ml_, np.int32).reshape(k, k, ml_))
+        finally:
+            lib().cusk_block_result_free(res)
+        return br, st
+
+
+class _Queue:
+    """Where a rank's workers get their next block from: the rank's own list (static assignment) or one counter
+    shared by all ranks in the job's c10d store (dynamic: blocks are handed out in descending predicted cost)."""
+
+    def __init__(self, order: list[int], store=None, key: str = "cusk_next_block"):
+        self.order, self.store, self.key = order, store, key
+        self.lock = threading.Lock()
+        self.pos = 0
+
+    def next(self):
+        if self.store is not None:
+            k = int(self.store.add(self.key, 1)) - 1
+        else:
+            with self.lock:
+                k = self.pos
+                self.pos += 1
+        return self.order[k] if k < len(self.order) else None
+
+
+def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None):
+    """Runs blocks from `queue` on GPU `device` with `inflight` engines (one host thread each).
+    -> (results sorted by block index, {block index: CuskBlockStats}).  `engine_factory` exists for the CPU tests of
+    the scheduling / gather logic (a stand-in block set that needs no device); the product always runs on Engine."""
+    inflight = max(1, int(inflight))
+    engines = [engine_factory() if engine_factory else Engine(device) for _ in range(inflight)]
+    for e in engines:
+        for k, v in (options or {}).items():
+            e.set_option(k, int(v))
+    results, stats, errors = [], {}, []
+    lock = threading.Lock()
+
+    def worker(eng):
+        try:
+            while True:
+                b = queue.next()
+                if b is None or errors:
+                    return
+                br, st = bs.run_block(eng, b)
+                with lock:
+                    stats[b] = st
+                    if br is not None:
+                        results.append(br)
+        except Exception as exc:  # noqa: BLE001 -- re-raised on the calling thread
+            errors.append(exc)
+
+    if inflight == 1:
+        worker(engines[0])
+    else:
+        threads = [threading.Thread(target=worker, args=(e,)) for e in engines]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    for e in engines:
+        e.close()
+    if errors:
+        raise errors[0]
+    return sorted(results, key=lambda r: r.block_index), stats
+
+
+def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: str = "lpt", collective_device=None,
+            options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block"):
+    """One rank's part of the job (call on every rank of an initialised process group, or without one for a
+    single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment)."""
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized()
+    rank = dist.get_rank(group) if distributed else 0
+    world = dist.get_world_size(group) if distributed else 1
+    costs = bs.costs()
+    if schedule == "dynamic" and distributed and world > 1:
+        order = sorted(range(bs.num_blocks), key=lambda b: (-costs[b], b))
+        store = dist.distributed_c10d._get_default_store()
+        queue = _Queue(order, store, store_key)
+        owned = None
+    else:
+        owned = shard.assign_blocks(costs, world)[rank]
+        queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
+    results, stats = run_rank(bs, queue, device, inflight, options, engine_factory)
+    if distributed:
+        allr = shard.gather_results(results, device=collective_device, group=group)
+    else:
+        allr = results
+    if rank == 0 and outdir is not None:
+        for r in allr:
+            r.write(outdir)
+    return allr, stats, (owned if owned is not None else sorted(stats))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="run_blocks", description="cusk on every LD block of a .blocks file, sharded over the GPUs of one node")
+    ap.add_argument("phen")
+    ap.add_argument("bfiles")
+    ap.add_argument("blocks")
+    ap.add_argument("alpha", type=float)
+    ap.add_argument("max_level", type=int)
+    ap.add_argument("max_level_two", type=int)
+    ap.add_argument("depth", type=int)
+    ap.add_argument("outdir")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo: CPU collectives)")
+    ap.add_argument("--inflight", type=int, default=2, help="blocks in flight per GPU")
+    ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
+    ap.add_argument("--device", type=int, default=None, help="GPU of this rank (default LOCAL_RANK modulo the device count)")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+
+    ndev = max(torch.cuda.device_count(), 1)
+    device = args.device if args.device is not None else local_rank % ndev
+    cdev = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if args.backend == "nccl":
+            torch.cuda.set_device(device)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+            cdev = torch.device("cuda", device)
+        else:
+            dist.init_process_group(args.backend)
+    if not os.path.isdir(args.outdir):
+        sys.exit(f"file or directory not found: {args.outdir}")
+    t0 = time.perf_counter()
+    bs = BlockSet(args.phen, args.bfiles, args.blocks, args.alpha, args.max_level, args.max_level_two, args.depth)
+    t_open = time.perf_counter() - t0
+    allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev)
+    dt = time.perf_counter() - t0
+    tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
+    print(f"[rank {rank}/{world}] gpu {device}: {len(stats)} blocks ({sum(1 for s in stats.values() if s.skipped)} skipped), "
+          f"{tests:.3e} CI tests, open {t_open:.2f} s, total {dt:.2f} s", flush=True)
+    if rank == 0:
+        print(f"Wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}", flush=True)
+    bs.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -124,6 +124,10 @@ const char *cusk_last_error(const cusk_engine *e);
  * cusk_sepselect_greedy for candidate lists too long for LDS, default 4 GiB; such pairs run in batches of what fits). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
+/* Makes the engine's device the calling thread's current HIP device, so that the cusk_dev_* helpers below act on it.
+ * Needed on multi-GPU nodes by threads other than the one that created the engine (HIP's current device is per thread
+ * and starts at 0). */
+int cusk_engine_bind_thread(cusk_engine *e);
 
 /* Row-sharded sweep of ONE block over several engines, normally one per GPU (a single matrix too
  * large or too slow for one device; the reference has no counterpart, its Skeleton is single-GPU, cuPC-S.cu:42-190).
@@ -220,6 +224,57 @@ int cusk_sepselect_greedy(cusk_engine *e, const double *trait_corr, long long n,
 /* out_host[a*k + b] = M_dev[idx[a]*n + idx[b]]: the retained sub-matrix of parent_set.cpp:84-238
  * (reduce_gc / reduce_gcs) without copying the n*n matrix to the host; idx_host has k entries. */
 int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host);
+
+/* ---------------------------------------------------------------------------
+ * (3) block driver: many LD blocks from one process
+ * ------------------------------------------------------------------------ */
+
+/* The reference processes one LD block per `mps cusk` invocation (src/cli.cpp:507-512, README.md:62) and leaves the
+ * loop over blocks to the job scheduler.  A block set holds what every such invocation loads again -- .phen, the
+ * <bfiles>.dim/.bim/.means/.stds, the .blocks file, the thresholds (cli.cpp:458-497) -- once, maps the .bed, and runs
+ * any of its blocks through exactly the code `mps cusk` runs for that block (host/block_pipeline.h), on whichever
+ * engine (= GPU) the caller hands in.  This is what the multi-GPU driver (ci-gwas_amd/run_blocks.py: one process per
+ * GPU, longest-processing-time assignment of blocks to ranks, one gather of the per-block results) is built on.
+ * A block set is read-only after open: several threads may run different blocks at once, each with its own engine. */
+typedef struct cusk_blockset cusk_blockset;
+typedef struct cusk_block_result cusk_block_result;
+
+typedef struct cusk_block_stats {
+    int skipped;            /* 1: no marginally significant marker-trait correlation (cli.cpp:561-576), no result */
+    int num_sig;            /* marker-trait correlations at or above Th[0] */
+    long long markers;      /* markers of the block */
+    long long retained;     /* markers in the result */
+    long long tests[2];     /* CI tests of stage one / stage two */
+    double ms_inputs, ms_corr, ms_stage1, ms_prune, ms_stage2, ms_reduce; /* wall-clock phases of this block */
+    cusk_stats stage[2];    /* engine counters of both stages */
+} cusk_block_stats;
+
+/* Same arguments as `mps cusk` without outdir and block index (cli.cpp:432-456).  On failure returns an error code
+ * and writes the message (what `mps cusk` would have printed before exit(1)) to err (may be NULL). */
+int cusk_blockset_open(cusk_blockset **out, const char *phen_path, const char *bfiles, const char *blocks_path,
+                       float alpha, int max_level, int max_level_two, int depth, char *err, size_t err_len);
+void cusk_blockset_close(cusk_blockset *bs);
+int cusk_blockset_num_blocks(const cusk_blockset *bs);
+long long cusk_blockset_num_samples(const cusk_blockset *bs);
+int cusk_blockset_num_phen(const cusk_blockset *bs);
+/* markers of block i and its output file stem "<chr>_<first>_<last>" (marker_block.h:36-60) */
+long long cusk_blockset_block_markers(const cusk_blockset *bs, int block_index);
+int cusk_blockset_block_stem(const cusk_blockset *bs, int block_index, char *stem, size_t stem_len);
+/* cli.cpp:521-677 for one block on e's device.  *out receives the result (NULL when the block is skipped);
+ * stats may be NULL.  Error text: cusk_blockset_last_error (per calling thread). */
+int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, cusk_block_result **out,
+                            cusk_block_stats *stats);
+const char *cusk_blockset_last_error(void);
+/* the reduced result of one block: what ReducedGCS::to_file writes (include/mps/parent_set.h:42-52) */
+void cusk_block_result_dims(const cusk_block_result *r, long long *num_var, long long *num_phen, long long *max_level);
+const char *cusk_block_result_stem(const cusk_block_result *r);
+const int *cusk_block_result_ixs(const cusk_block_result *r);    /* num_var */
+const int *cusk_block_result_adj(const cusk_block_result *r);    /* num_var^2 */
+const float *cusk_block_result_corr(const cusk_block_result *r); /* num_var^2 */
+const int *cusk_block_result_sep(const cusk_block_result *r);    /* num_var^2 * max_level */
+/* <outdir>/<stem>.mdim .ixs .adj .corr .sep */
+int cusk_block_result_write(const cusk_block_result *r, const char *outdir);
+void cusk_block_result_free(cusk_block_result *r);
 
 /* device memory helpers so that C hosts need no HIP headers */
 void *cusk_dev_alloc(size_t bytes);

@@ -1,0 +1,102 @@
+"""CPU, world_size 2 over gloo: the block driver's scheduling (static LPT and the shared-counter dynamic queue), its
+worker threads and the one gather, with a stand-in block set whose blocks are computed by the oracle (the kernels are
+not under test here; tests/test_gpu_run_blocks.py runs the same driver on the real engine)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+NBLOCKS = 7
+SIZES = [60 + 23 * ((5 * b) % NBLOCKS) for b in range(NBLOCKS)]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Stats:
+    def __init__(self, skipped):
+        self.skipped = skipped
+        self.tests = [1, 1]
+
+
+class _NoEngine:
+    def set_option(self, k, v):
+        pass
+
+    def close(self):
+        pass
+
+
+class _OracleBlockSet:
+    """block b: synthetic correlation block of SIZES[b] markers + 4 traits; block 3 is 'skipped'"""
+    num_blocks, num_samples, num_phen = NBLOCKS, 2000, 4
+
+    def markers(self, i):
+        return SIZES[i]
+
+    def costs(self):
+        from cigwas_amd import shard
+
+        return [shard.predicted_cost(m, self.num_samples, self.num_phen) for m in SIZES]
+
+    def run_block(self, eng, b):
+        from cigwas_amd import shard, synth
+        from oracle import oracle as O
+
+        if b == 3:
+            return None, _Stats(1)
+        Cm = synth.synth_corr_block(SIZES[b], 4, N=2000, block_index=b)
+        red = O.cusk_from_corr(Cm, 4, O.threshold_array(2000, 1e-3), 2, 3, 1)
+        return shard.BlockResult(b, f"1_{b}_{b}", 4, red.max_level, red.new_to_old, red.G, red.C, red.S), _Stats(0)
+
+
+def _worker(rank, world, port, outdir, schedule, q):
+    import sys
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cigwas_amd import run_blocks as rb
+
+    allr, stats, owned = rb.run_job(_OracleBlockSet(), outdir, device=0, inflight=2, schedule=schedule,
+                                    engine_factory=_NoEngine, store_key=f"next_{schedule}")
+    assert (allr is None) == (rank != 0)
+    q.put((rank, sorted(stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("schedule", ["lpt", "dynamic"])
+def test_two_rank_block_driver_partitions_and_gathers(tmp_path, oracle, synth, schedule):
+    import torch.multiprocessing as mp
+
+    from cigwas_amd import shard
+
+    out = tmp_path / schedule
+    out.mkdir()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_worker, args=(2, _free_port(), str(out), schedule, q), nprocs=2, join=True)
+    ran = dict(q.get() for _ in range(2))
+    assert sorted(ran[0] + ran[1]) == list(range(NBLOCKS))  # a partition: every block exactly once
+    if schedule == "lpt":
+        owned = shard.assign_blocks(_OracleBlockSet().costs(), 2)
+        assert ran[0] == owned[0] and ran[1] == owned[1]
+    stems = sorted({f.rsplit(".", 1)[0] for f in os.listdir(out)})
+    assert stems == [f"1_{b}_{b}" for b in range(NBLOCKS) if b != 3]
+    for b in (0, 6):
+        Cm = synth.synth_corr_block(SIZES[b], 4, N=2000, block_index=b)
+        red = oracle.cusk_from_corr(Cm, 4, oracle.threshold_array(2000, 1e-3), 2, 3, 1)
+        oracle.write_reduced(red, str(tmp_path / f"ref_{b}"), with_sep=True)
+        for ext in (".mdim", ".ixs", ".adj", ".corr", ".sep"):
+            assert open(str(out / f"1_{b}_{b}") + ext, "rb").read() == open(str(tmp_path / f"ref_{b}") + ext, "rb").read()
