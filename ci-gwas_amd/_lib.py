@@ -68,6 +68,7 @@ SYMBOLS = {
     "cusk_engine_set_option": (_i, [_vp, C.c_char_p, _ll]),
     "cusk_engine_stream": (_vp, [_vp]),
     "cusk_engine_bind_thread": (_i, [_vp]),
+    "cusk_engine_device": (_i, [_vp]),
     "cusk_engine_set_row_shard": (_i, [_vp, _i, _i, _vp, _vp, _i]),
     "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
@@ -85,6 +86,7 @@ SYMBOLS = {
     "cusk_hanning_smooth": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
     "cusk_sepselect_greedy": (_i, [_vp, _vp, C.c_longlong, _i, C.c_longlong, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cusk_gather_submatrix": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
+    "cusk_gather_submatrix_dev": (_i, [_vp, _vp, _i, _vp, _i, _vp]),
     "cusk_blockset_open": (_i, [C.POINTER(_vp), C.c_char_p, C.c_char_p, C.c_char_p, _f, _i, _i, _i, C.c_char_p, _sz]),
     "cusk_blockset_close": (None, [_vp]),
     "cusk_blockset_num_blocks": (_i, [_vp]),
@@ -92,6 +94,7 @@ SYMBOLS = {
     "cusk_blockset_num_phen": (_i, [_vp]),
     "cusk_blockset_block_markers": (_ll, [_vp, _i]),
     "cusk_blockset_block_stem": (_i, [_vp, _i, C.c_char_p, _sz]),
+    "cusk_blockset_stage": (_i, [_vp, _vp]),
     "cusk_blockset_run_block": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
     "cusk_blockset_last_error": (C.c_char_p, []),
     "cusk_block_result_dims": (None, [_vp, C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),

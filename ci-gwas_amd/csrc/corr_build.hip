@@ -934,6 +934,18 @@ __global__ void extract_tri_kernel(const float *__restrict__ C, float *out, size
     out[lin] = C[(lo + i) * n + lo + j];
 }
 
+// true when p is a HIP device allocation (hipPointerGetAttributes fails for plain host memory: not an error here)
+static bool is_device_pointer(const void *p)
+{
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess)
+    {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeDevice;
+}
+
 int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N, size_t p,
                     const float *mean, const float *std, float *C_dev, float *mxp_host, float *mxm_tri_host,
                     float *pxp_tri_host)
@@ -942,15 +954,43 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     CUSK_HIP(e, hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const size_t clb = (N + 3) / 4, w64 = (N + 63) / 64, n = m + p;
-    CUSK_HIP(e, e->bed_dev.ensure(m * clb));
-    CUSK_HIP(e, e->phen_dev.ensure(sizeof(float) * std::max<size_t>(p * N, 1)));
-    CUSK_HIP(e, e->mean_dev.ensure(sizeof(float) * m));
-    CUSK_HIP(e, e->std_dev.ensure(sizeof(float) * m));
+    // Inputs that already live in HBM (a whole .bed staged once per GPU by the block driver, cusk_blockset_stage)
+    // are used where they are; host inputs are copied to engine scratch first.
+    const unsigned char *bed_d = nullptr;
+    const float *phen_d = nullptr, *mean_d = nullptr, *std_d = nullptr;
     CUSK_HIP(e, hipEventRecord(e->ev_corr[0], s));
-    CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
-    if (p) CUSK_HIP(e, hipMemcpyAsync(e->phen_dev.p, phen, sizeof(float) * p * N, hipMemcpyHostToDevice, s));
-    CUSK_HIP(e, hipMemcpyAsync(e->mean_dev.p, mean, sizeof(float) * m, hipMemcpyHostToDevice, s));
-    CUSK_HIP(e, hipMemcpyAsync(e->std_dev.p, std, sizeof(float) * m, hipMemcpyHostToDevice, s));
+    if (is_device_pointer(bed))
+        bed_d = bed;
+    else
+    {
+        CUSK_HIP(e, e->bed_dev.ensure(m * clb));
+        CUSK_HIP(e, hipMemcpyAsync(e->bed_dev.p, bed, m * clb, hipMemcpyHostToDevice, s));
+        bed_d = e->bed_dev.as<unsigned char>();
+    }
+    if (is_device_pointer(phen))
+        phen_d = phen;
+    else
+    {
+        CUSK_HIP(e, e->phen_dev.ensure(sizeof(float) * std::max<size_t>(p * N, 1)));
+        if (p) CUSK_HIP(e, hipMemcpyAsync(e->phen_dev.p, phen, sizeof(float) * p * N, hipMemcpyHostToDevice, s));
+        phen_d = e->phen_dev.as<float>();
+    }
+    if (is_device_pointer(mean))
+        mean_d = mean;
+    else
+    {
+        CUSK_HIP(e, e->mean_dev.ensure(sizeof(float) * m));
+        CUSK_HIP(e, hipMemcpyAsync(e->mean_dev.p, mean, sizeof(float) * m, hipMemcpyHostToDevice, s));
+        mean_d = e->mean_dev.as<float>();
+    }
+    if (is_device_pointer(std))
+        std_d = std;
+    else
+    {
+        CUSK_HIP(e, e->std_dev.ensure(sizeof(float) * m));
+        CUSK_HIP(e, hipMemcpyAsync(e->std_dev.p, std, sizeof(float) * m, hipMemcpyHostToDevice, s));
+        std_d = e->std_dev.as<float>();
+    }
     float *mxp_d = nullptr;
     if (mxp_host && p)
     {
@@ -963,7 +1003,7 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         // cross-check path: bit planes + AND/popcount (no matrix cores)
         CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
         hipLaunchKernelGGL(bed_to_bitplanes_kernel, dim3((unsigned)((m * w64 + 255) / 256)), dim3(256), 0, s,
-                           e->bed_dev.as<unsigned char>(), e->planes.as<unsigned long long>(), m, N, clb, w64);
+                           bed_d, e->planes.as<unsigned long long>(), m, N, clb, w64);
         CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kTile - 1) / kTile);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
@@ -976,15 +1016,15 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kMT - 1) / kMT);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
-        const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 15u) == 0);
+        const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_d) & 15u) == 0);
         if (e->opt_corr_fp4 && rows16)
-            hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
+            hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev,
                                m, N, clb, n, tiles, (size_t)0);
         else if (e->opt_corr_fp4)
-            hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev,
+            hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev,
                                m, N, clb, n, tiles, (size_t)0);
         else
-            hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->bed_dev.as<unsigned char>(), C_dev, m,
+            hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev, m,
                                N, clb, n, tiles);
         hipLaunchKernelGGL(unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, C_dev, n);
     }
@@ -997,25 +1037,25 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     {
         const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
         if (e->opt_corr_popcount)
-            hipLaunchKernelGGL(mxp_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
-                               e->phen_dev.as<float>(), e->mean_dev.as<float>(), e->std_dev.as<float>(), C_dev, mxp_d, m, N,
+            hipLaunchKernelGGL(mxp_kernel, dim3((unsigned)((m + 3) / 4)), dim3(256), 0, s, bed_d,
+                               phen_d, mean_d, std_d, C_dev, mxp_d, m, N,
                                p, clb, n, p0, pc);
         else
         {
-            const bool fast = (clb % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 3u) == 0) &&
-                              ((reinterpret_cast<uintptr_t>(e->phen_dev.p) & 15u) == 0);
+            const bool fast = (clb % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(bed_d) & 3u) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(phen_d) & 15u) == 0);
             if (fast)
                 hipLaunchKernelGGL(mxp_mfma_kernel<true>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
-                                   e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
-                                   e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+                                   bed_d, phen_d, mean_d,
+                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
             else
                 hipLaunchKernelGGL(mxp_mfma_kernel<false>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
-                                   e->bed_dev.as<unsigned char>(), e->phen_dev.as<float>(), e->mean_dev.as<float>(),
-                                   e->std_dev.as<float>(), C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+                                   bed_d, phen_d, mean_d,
+                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
         }
     }
     if (C_dev && p > 1)
-        hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, e->phen_dev.as<float>(), C_dev, m,
+        hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, phen_d, C_dev, m,
                            N, p, n);
     CUSK_HIP(e, hipGetLastError());
     CUSK_HIP(e, hipEventRecord(e->ev_corr[4], s));

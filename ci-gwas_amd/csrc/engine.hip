@@ -683,6 +683,7 @@ extern "C" int cusk_engine_set_row_shard(cusk_engine *e, int rank, int world, cu
 
 extern "C" const char *cusk_last_error(const cusk_engine *e) { return e ? e->err.c_str() : "no engine"; }
 extern "C" void *cusk_engine_stream(const cusk_engine *e) { return e ? (void *)e->stream : nullptr; }
+extern "C" int cusk_engine_device(const cusk_engine *e) { return e ? e->device : -1; }
 extern "C" int cusk_engine_bind_thread(cusk_engine *e)
 {
     if (!e) return CUSK_ERR_ARG;
@@ -837,6 +838,20 @@ extern "C" int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, 
     if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
     (void)hipFree(idx_d);
     (void)hipFree(out_d);
+    if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    return CUSK_OK;
+}
+
+extern "C" int cusk_gather_submatrix_dev(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_dev)
+{
+    if (!e || !M_dev || !idx_host || !out_dev || k <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    int *idx_d = nullptr;
+    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&idx_d), sizeof(int) * (size_t)k));
+    hipError_t st = hipMemcpyAsync(idx_d, idx_host, sizeof(int) * (size_t)k, hipMemcpyHostToDevice, e->stream);
+    if (st == hipSuccess) st = launch_gather_sub(M_dev, n, idx_d, k, out_dev, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    (void)hipFree(idx_d);
     if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
     return CUSK_OK;
 }

@@ -14,6 +14,17 @@ struct cusk_blockset
     // with the block set
     std::mutex mu;
     std::map<cusk_engine *, std::unique_ptr<BlockScratch>> scratch;
+    std::map<int, StagedInputs> staged;  // by device ordinal
+    const StagedInputs *staged_of(cusk_engine *e)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = staged.find(cusk_engine_device(e));
+        return it == staged.end() ? nullptr : &it->second;
+    }
+    ~cusk_blockset()
+    {
+        for (auto &kv : staged) kv.second.release();
+    }
     BlockScratch &scratch_of(cusk_engine *e)
     {
         std::lock_guard<std::mutex> lock(mu);
@@ -91,6 +102,34 @@ extern "C" int cusk_blockset_block_stem(const cusk_blockset *bs, int i, char *st
     return CUSK_OK;
 }
 
+extern "C" int cusk_blockset_stage(cusk_blockset *bs, cusk_engine *e)
+{
+    if (!bs || !e) return CUSK_ERR_ARG;
+    if (bs->staged_of(e)) return CUSK_OK;
+    if (cusk_engine_bind_thread(e) != CUSK_OK) return CUSK_ERR_HIP;
+    const CuskInputs &in = bs->in;
+    const size_t bed_bytes = in.bed.size > 3 ? in.bed.size - 3 : 0, pad = 4096;
+    StagedInputs st;
+    st.bed = static_cast<unsigned char *>(cusk_dev_alloc(bed_bytes + pad));
+    st.phen = static_cast<float *>(cusk_dev_alloc(sizeof(float) * in.phen.data.size() + pad));
+    st.means = static_cast<float *>(cusk_dev_alloc(sizeof(float) * in.means_all.size() + pad));
+    st.stds = static_cast<float *>(cusk_dev_alloc(sizeof(float) * in.stds_all.size() + pad));
+    bool ok = st.bed && st.phen && st.means && st.stds;
+    ok = ok && cusk_dev_upload(st.bed, in.bed.data + 3, bed_bytes) == CUSK_OK;
+    ok = ok && cusk_dev_upload(st.phen, in.phen.data.data(), sizeof(float) * in.phen.data.size()) == CUSK_OK;
+    ok = ok && cusk_dev_upload(st.means, in.means_all.data(), sizeof(float) * in.means_all.size()) == CUSK_OK;
+    ok = ok && cusk_dev_upload(st.stds, in.stds_all.data(), sizeof(float) * in.stds_all.size()) == CUSK_OK;
+    if (!ok)
+    {
+        st.release();
+        copy_err("staging the block set's inputs on the device failed (not enough device memory?)", nullptr, 0);
+        return CUSK_ERR_HIP;
+    }
+    std::lock_guard<std::mutex> lock(bs->mu);
+    bs->staged[cusk_engine_device(e)] = st;
+    return CUSK_OK;
+}
+
 extern "C" int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, cusk_block_result **out,
                                        cusk_block_stats *stats)
 {
@@ -101,7 +140,7 @@ extern "C" int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int bl
     BlockStats st;
     try
     {
-        const bool kept = run_cusk_block(e, bs->in, block_index, scratch, res->r, res->stem, st, nullptr);
+        const bool kept = run_cusk_block(e, bs->in, block_index, scratch, res->r, res->stem, st, nullptr, bs->staged_of(e));
         if (stats)
         {
             stats->skipped = st.skipped;

@@ -291,6 +291,23 @@ struct CuskInputs
     size_t first_marker(const Block &b) const { return bim.start_of(b.chr) + b.first; }
 };
 
+// the inputs all blocks share, resident on one device (cusk_blockset_stage): marker g's genotypes start at
+// bed + g * bytes_per_col, means / stds are indexed by global marker
+struct StagedInputs
+{
+    unsigned char *bed = nullptr;
+    float *phen = nullptr, *means = nullptr, *stds = nullptr;
+    void release()
+    {
+        cusk_dev_free(bed);
+        cusk_dev_free(phen);
+        cusk_dev_free(means);
+        cusk_dev_free(stds);
+        bed = nullptr;
+        phen = means = stds = nullptr;
+    }
+};
+
 struct BlockStats
 {
     int skipped = 0;         // cli.cpp:572-576: no marginally significant marker-trait correlation, no output
@@ -312,7 +329,7 @@ struct BlockScratch
 
 // cli.cpp:521-677 for blocks[block_index] on the engine's device.  Returns false when the block is skipped.
 inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index, BlockScratch &scr, Reduced &out,
-                           std::string &stem, BlockStats &bs, std::ostream *log)
+                           std::string &stem, BlockStats &bs, std::ostream *log, const StagedInputs *staged = nullptr)
 {
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point &t) {
@@ -339,9 +356,17 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
     const size_t bpc = in.dims.bytes_per_col();
     if (3 + (g1 + 1) * bpc > in.bed.size) die("bed file is shorter than .dim / .bim say");
     const unsigned char *bed = in.bed.data + 3 + g0 * bpc;  // io.cpp:238-249
+    const float *phen = in.phen.data.data();
     std::vector<float> means_v, stds_v;
     const float *means, *stds;
-    if (!in.means_all.empty())
+    if (staged)
+    {  // device-resident inputs: no per-block PCIe traffic
+        bed = staged->bed + g0 * bpc;
+        phen = staged->phen;
+        means = staged->means + g0;
+        stds = staged->stds + g0;
+    }
+    else if (!in.means_all.empty())
     {
         if (g1 >= in.means_all.size() || g1 >= in.stds_all.size()) die("block size and number of means or stds differ");
         means = in.means_all.data() + g0;
@@ -365,7 +390,7 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
         *log << "Computing all correlations" << std::endl;
     }
     std::vector<float> mxp(m * p);
-    if (cusk_corr_build(e, bed, in.phen.data.data(), m, N, p, means, stds, scr.C.p, mxp.data()) != CUSK_OK)
+    if (cusk_corr_build(e, bed, phen, m, N, p, means, stds, scr.C.p, mxp.data()) != CUSK_OK)
         engine_die("correlation build", e);
     bs.ms_corr = ms_since(t);
     // cli.cpp:561-576: blocks without any marginally significant marker-trait correlation are skipped
@@ -408,14 +433,15 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
     gcs.num_phen = p;
     gcs.max_level = (size_t)in.max_level;
     gcs.new_to_old = P;
-    gcs.C = gather(e, scr.C.p, (int)n, P);
+    // cli.cpp:62-87: the retained sub-matrix is the input of stage two -- gathered device to device
+    const int k = (int)gcs.num_var;
+    scr.C2.reserve((size_t)k * k);
+    if (cusk_gather_submatrix_dev(e, scr.C.p, (int)n, P.data(), k, scr.C2.p) != CUSK_OK) engine_die("gather", e);
     bs.ms_prune = ms_since(t);
     // (the stage-one separating sets of cli.cpp:673 are never read again: stage two recomputes them)
 
     if (log) *log << "Starting second cusk stage" << std::endl;
-    // cli.cpp:62-87: Skeleton again on the reduced set, starting from the complete graph
-    const int k = (int)gcs.num_var;
-    scr.C2.upload(gcs.C);
+    // Skeleton again on the reduced set, starting from the complete graph
     cusk_engine_set_option(e, "assume_symmetric", 0);
     cusk_stats &st2 = bs.stage[1];
     if (cusk_run_skeleton(e, scr.C2.p, k, in.Th, in.max_level_two, &st2) != CUSK_OK) engine_die("Skeleton (stage two)", e);

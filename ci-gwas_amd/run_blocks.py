@@ -73,6 +73,10 @@ class BlockSet:
             raise IndexError(i)
         return buf.value.decode()
 
+    def stage(self, eng: Engine) -> bool:
+        """cusk_blockset_stage: the whole .bed, the phenotypes, means and stds to the engine's GPU, once"""
+        return lib().cusk_blockset_stage(self.h, eng.h) == 0
+
     def costs(self) -> list[float]:
         return [shard.predicted_cost(self.markers(i), self.num_samples, self.num_phen) for i in range(self.num_blocks)]
 
@@ -125,7 +129,8 @@ class _Queue:
         return self.order[k] if k < len(self.order) else None
 
 
-def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None):
+def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None,
+             stage: bool = True):
     """Runs blocks from `queue` on GPU `device` with `inflight` engines (one host thread each).
     -> (results sorted by block index, {block index: CuskBlockStats}).  `engine_factory` exists for the CPU tests of
     the scheduling / gather logic (a stand-in block set that needs no device); the product always runs on Engine."""
@@ -134,6 +139,8 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
     for e in engines:
         for k, v in (options or {}).items():
             e.set_option(k, int(v))
+    if stage and hasattr(bs, "stage"):
+        bs.stage(engines[0])  # best effort: without it every block uploads its own slice
     results, stats, errors = [], {}, []
     lock = threading.Lock()
 
@@ -167,7 +174,8 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
 
 
 def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: str = "lpt", collective_device=None,
-            options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block"):
+            options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block",
+            stage: bool = True):
     """One rank's part of the job (call on every rank of an initialised process group, or without one for a
     single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment)."""
     import torch.distributed as dist
@@ -184,7 +192,7 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
     else:
         owned = shard.assign_blocks(costs, world)[rank]
         queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
-    results, stats = run_rank(bs, queue, device, inflight, options, engine_factory)
+    results, stats = run_rank(bs, queue, device, inflight, options, engine_factory, stage)
     if distributed:
         allr = shard.gather_results(results, device=collective_device, group=group)
     else:
@@ -206,8 +214,9 @@ def main(argv=None):
     ap.add_argument("depth", type=int)
     ap.add_argument("outdir")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo: CPU collectives)")
-    ap.add_argument("--inflight", type=int, default=2, help="blocks in flight per GPU")
+    ap.add_argument("--inflight", type=int, default=1, help="blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
+    ap.add_argument("--no-stage", action="store_true", help="do not keep the whole .bed in HBM; every block uploads its slice")
     ap.add_argument("--device", type=int, default=None, help="GPU of this rank (default LOCAL_RANK modulo the device count)")
     args = ap.parse_args(argv)
 
@@ -233,7 +242,7 @@ def main(argv=None):
     t0 = time.perf_counter()
     bs = BlockSet(args.phen, args.bfiles, args.blocks, args.alpha, args.max_level, args.max_level_two, args.depth)
     t_open = time.perf_counter() - t0
-    allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev)
+    allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage)
     dt = time.perf_counter() - t0
     tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
     print(f"[rank {rank}/{world}] gpu {device}: {len(stats)} blocks ({sum(1 for s in stats.values() if s.skipped)} skipped), "

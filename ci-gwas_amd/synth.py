@@ -314,3 +314,75 @@ def merged_skeleton(seed: int, p: int, m: int, duplicates: int = 0, with_prior: 
         for k in rng.choice(ii.size, size=min(3, ii.size), replace=False) if ii.size else []:
             prior[jj[k], ii[k]] = 1
     return adj, corr, ixs, prior
+
+
+# ---------------------------------------------------------------------------
+# whole-chromosome file sets (BASELINE.json config 4: ~200 LD blocks x ~500 SNPs x 20 traits)
+# ---------------------------------------------------------------------------
+def chromosome_block_sizes(nblocks: int, seed: int = 0, mean: int = 500, lo: int = 100, hi: int = 2000, quantum: int = 100):
+    """Unequal LD-block sizes (multiples of the LD window): log-normal around `mean`, clipped to [lo, hi].  Block b's
+    size depends on (seed, b) only, so a job with more ranks extends the same chromosome."""
+    out = []
+    for b in range(nblocks):
+        r = np.random.Generator(np.random.PCG64(BASE_SEED + 7919 * (seed + 1) + b))
+        s = mean * float(np.exp(r.normal(-0.1, 0.6)))
+        out.append(int(min(hi, max(lo, quantum * round(s / quantum)))))
+    return out
+
+
+def chromosome_segment(sizes, seg_first: int, seg_last: int, N: int, p: int, seed: int = 0, **kw):
+    """Genotypes of blocks seg_first..seg_last-1 of the chromosome `sizes` (own RNG stream per block) and their
+    genetic contribution to the p traits: (G int8 [m_seg, N], contrib float64 [p, N]).  Each trait gets
+    5 causal SNPs per 1,000 with |beta| ~ U(0.02, 0.08) as in make_traits."""
+    Gs, contrib = [], np.zeros((p, N), np.float64)
+    for b in range(seg_first, seg_last):
+        rng = np.random.Generator(np.random.PCG64(BASE_SEED + 104729 * (seed + 1) + b))
+        G = make_genotypes(sizes[b], N, rng, **kw)
+        g = G.astype(np.float32)
+        g[G < 0] = np.nan
+        mu = np.nanmean(g, axis=1, keepdims=True)
+        sd = np.nanstd(g, axis=1, keepdims=True)
+        sd[sd == 0] = 1.0
+        ncausal_f = 5.0 * sizes[b] / 1000.0
+        for k in range(p):
+            nc = int(ncausal_f) + (1 if rng.random() < ncausal_f - int(ncausal_f) else 0)
+            if nc == 0:
+                continue
+            idx = rng.choice(sizes[b], size=nc, replace=False)
+            beta = rng.uniform(0.02, 0.08, size=nc) * rng.choice([-1.0, 1.0], size=nc)
+            contrib[k] += beta @ np.nan_to_num((g[idx] - mu[idx]) / sd[idx]).astype(np.float64)
+        Gs.append(G)
+    return np.concatenate(Gs, axis=0), contrib
+
+
+def chromosome_traits(contrib: np.ndarray, seed: int = 0) -> np.ndarray:
+    """p x N float32 standardised traits from the summed genetic contributions: lower-triangular trait DAG
+    (edge probability 3/p, |b| ~ U(0.05, 0.2)) + unit noise, as make_traits."""
+    p, N = contrib.shape
+    rng = np.random.Generator(np.random.PCG64(BASE_SEED + 15485863 * (seed + 1)))
+    Y = np.zeros((p, N), np.float64)
+    for k in range(p):
+        y = contrib[k].copy()
+        for k2 in range(k):
+            if rng.random() < 3.0 / p:
+                y = y + rng.uniform(0.05, 0.2) * rng.choice([-1.0, 1.0]) * Y[k2]
+        y = y + rng.standard_normal(N)
+        Y[k] = (y - y.mean()) / y.std()
+    return Y.astype(np.float32)
+
+
+def write_blocks_file(path: str, sizes, chr_id: str = "1") -> None:
+    first = 0
+    with open(path, "w") as f:
+        for s in sizes:
+            f.write(f"{chr_id}\t{first}\t{first + s - 1}\n")
+            first += s
+
+
+def write_phen_fast(path: str, Y: np.ndarray) -> None:
+    """same format as write_phen (header + `FID IID v1..vp` rows), %.9g values, written in one go"""
+    p, N = Y.shape
+    cols = Y.T.astype(np.float64)
+    with open(path, "w") as f:
+        f.write("FID IID " + " ".join(f"T{k}" for k in range(p)) + "\n")
+        f.write("".join(f"f{i} i{i} " + " ".join("NA" if np.isnan(v) else "%.9g" % v for v in cols[i]) + "\n" for i in range(N)))

@@ -128,6 +128,7 @@ void *cusk_engine_stream(const cusk_engine *e);
  * Needed on multi-GPU nodes by threads other than the one that created the engine (HIP's current device is per thread
  * and starts at 0). */
 int cusk_engine_bind_thread(cusk_engine *e);
+int cusk_engine_device(const cusk_engine *e); /* the HIP device ordinal the engine was created on */
 
 /* Row-sharded sweep of ONE block over several engines, normally one per GPU (a single matrix too
  * large or too slow for one device; the reference has no counterpart, its Skeleton is single-GPU, cuPC-S.cu:42-190).
@@ -224,6 +225,9 @@ int cusk_sepselect_greedy(cusk_engine *e, const double *trait_corr, long long n,
 /* out_host[a*k + b] = M_dev[idx[a]*n + idx[b]]: the retained sub-matrix of parent_set.cpp:84-238
  * (reduce_gc / reduce_gcs) without copying the n*n matrix to the host; idx_host has k entries. */
 int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_host);
+/* the same with the k*k result left on the device (the stage-two matrix of reduced_gcs_cusk, cli.cpp:62-87, never
+ * visits the host) */
+int cusk_gather_submatrix_dev(cusk_engine *e, const float *M_dev, int n, const int *idx_host, int k, float *out_dev);
 
 /* ---------------------------------------------------------------------------
  * (3) block driver: many LD blocks from one process
@@ -260,6 +264,12 @@ int cusk_blockset_num_phen(const cusk_blockset *bs);
 /* markers of block i and its output file stem "<chr>_<first>_<last>" (marker_block.h:36-60) */
 long long cusk_blockset_block_markers(const cusk_blockset *bs, int block_index);
 int cusk_blockset_block_stem(const cusk_blockset *bs, int block_index, char *stem, size_t stem_len);
+/* Copies the inputs every block reads -- the packed genotypes of the whole .bed, the phenotypes, the marker means and
+ * standard deviations -- to e's device once (288 GB of HBM hold a whole-genome .bed); blocks run on any engine of that
+ * device then build their correlations straight from HBM (cusk_corr_build accepts device pointers) instead of copying
+ * their slice over PCIe every time.  Optional: without it every block uploads its own slice.  Returns
+ * CUSK_ERR_HIP (and stages nothing) when the device memory is not there.  Call before running blocks on that device. */
+int cusk_blockset_stage(cusk_blockset *bs, cusk_engine *e);
 /* cli.cpp:521-677 for one block on e's device.  *out receives the result (NULL when the block is skipped);
  * stats may be NULL.  Error text: cusk_blockset_last_error (per calling thread). */
 int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, cusk_block_result **out,

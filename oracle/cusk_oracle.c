@@ -845,6 +845,121 @@ void orc_hetcor_skeleton(const float *C, int n, int *G, const float *N, float th
 }
 
 /* ------------------------------------------------------------------ */
+/* CPU baseline variant: PC-stable in double precision with the test   */
+/* of pcalg::gaussCItest                 */
+/* ------------------------------------------------------------------ */
+
+/* The named baseline of BASELINE.json is pcalg::skeleton(method = "stable", indepTest = gaussCItest); pcalg is not
+ * in the reference tree and R is not in this image, so this is the same algorithm from pcalg's documented
+ * behaviour: order-independent level sweep on frozen neighbour lists, partial correlation of (X, Y | S) in double
+ * precision (Cholesky of C[S,S], Schur complement), edge removed when sqrt(N - |S| - 3) * |atanh r| <= qnorm(1 -
+ * alpha/2).  OpenMP over rows.  G (n*n, out) and tests[0..14]; returns the last level run.  Not a parity oracle:
+ * at threshold-borderline tests and singular sets it may differ from the fp32 reference arithmetic. */
+int orc_pcstable_f64(const float *C, int n, int *G, double nsamples, double alpha, int maxlevel, long long *tests)
+{
+    size_t nn = (size_t)n;
+    const double q = fabs(orc_qnorm(alpha / 2.0));
+    for (int i = 0; i <= ORC_ML; i++) tests[i] = 0;
+    int l;
+    for (l = 0; l <= ORC_ML && l <= maxlevel; l++) {
+        const double cut = q / sqrt(nsamples - (double)l - 3.0);
+        if (l == 0) {
+#pragma omp parallel for schedule(static)
+            for (int row = 0; row < n; row++) {
+                for (int col = 0; col < n; col++) {
+                    double r = (double)C[row * nn + col];
+                    G[row * nn + col] = (row != col) && !(fabs(atanh(r)) <= cut);
+                }
+            }
+            tests[0] = (long long)nn * (long long)(nn - 1) / 2;
+            continue;
+        }
+        nbrlist nl;
+        build_nbr(G, n, &nl);
+        if (nl.maxdeg - 1 < l) {
+            free(nl.off);
+            free(nl.nbr);
+            l = l - 1;
+            break;
+        }
+        unsigned char *found = (unsigned char *)calloc((size_t)nl.off[n] + 1, 1);
+        long long cnt = 0;
+#pragma omp parallel for schedule(dynamic, 8) reduction(+ : cnt)
+        for (int X = 0; X < n; X++) {
+            const int d = nl.off[X + 1] - nl.off[X];
+            const int *adj = nl.nbr + nl.off[X];
+            unsigned char *fx = found + nl.off[X];
+            if (d <= l) continue;
+            int idx[ORC_ML], S[ORC_ML];
+            double L[ORC_ML][ORC_ML], wx[ORC_ML], wy[ORC_ML];
+            for (int i = 0; i < l; i++) idx[i] = i;
+            int nfound = 0;
+            do {
+                for (int i = 0; i < l; i++) S[i] = adj[idx[i]];
+                /* Cholesky of C[S,S] (unit diagonal), then w_x = L^-1 C[S,X] */
+                int ok = 1;
+                for (int i = 0; i < l && ok; i++) {
+                    for (int j = 0; j <= i; j++) {
+                        double a = (i == j) ? 1.0 : (double)C[(size_t)S[i] * nn + S[j]];
+                        for (int k = 0; k < j; k++) a -= L[i][k] * L[j][k];
+                        if (i == j) {
+                            if (!(a > 1e-14)) { ok = 0; break; }
+                            L[i][i] = sqrt(a);
+                        } else
+                            L[i][j] = a / L[j][j];
+                    }
+                }
+                double hxx = 1.0;
+                if (ok) {
+                    for (int i = 0; i < l; i++) {
+                        double a = (double)C[(size_t)S[i] * nn + X];
+                        for (int k = 0; k < i; k++) a -= L[i][k] * wx[k];
+                        wx[i] = a / L[i][i];
+                        hxx -= wx[i] * wx[i];
+                    }
+                }
+                for (int k2 = 0; k2 < d; k2++) {
+                    int inS = 0;
+                    for (int i = 0; i < l; i++) inS |= (idx[i] == k2);
+                    if (inS || fx[k2]) continue;
+                    int Y = adj[k2];
+                    cnt++;
+                    if (!ok) continue; /* singular conditioning set: NA test, edge kept (the reference's behaviour) */
+                    double hyy = 1.0, hxy = (double)C[(size_t)X * nn + Y];
+                    for (int i = 0; i < l; i++) {
+                        double a = (double)C[(size_t)S[i] * nn + Y];
+                        for (int k = 0; k < i; k++) a -= L[i][k] * wy[k];
+                        wy[i] = a / L[i][i];
+                        hyy -= wy[i] * wy[i];
+                        hxy -= wx[i] * wy[i];
+                    }
+                    double r = hxy / sqrt(hxx * hyy);
+                    if (r > 1.0) r = 1.0;
+                    if (r < -1.0) r = -1.0;
+                    if (fabs(atanh(r)) <= cut) {
+                        fx[k2] = 1;
+                        nfound++;
+                    }
+                }
+                if (nfound == d) break;
+            } while (next_comb(idx, l, d));
+        }
+        tests[l] = cnt;
+        for (int X = 0; X < n; X++)
+            for (int k = nl.off[X]; k < nl.off[X + 1]; k++)
+                if (found[k]) {
+                    int Y = nl.nbr[k];
+                    G[(size_t)X * nn + Y] = 0;
+                    G[(size_t)Y * nn + X] = 0;
+                }
+        free(found);
+        free(nl.off);
+        free(nl.nbr);
+    }
+    return l;
+}
+
+/* ------------------------------------------------------------------ */
 /* correlation build: corr_kernels.cu                                  */
 /* ------------------------------------------------------------------ */
 

@@ -58,6 +58,8 @@ def lib():
         L.orc_ci_test.argtypes = [f32p, C.c_int, C.c_int, C.c_int, i32p, C.c_int, C.POINTER(C.c_float)]
         L.orc_skeleton.argtypes = [f32p, C.c_int, i32p, f32p, C.POINTER(C.c_int), C.c_int, f32p, i32p, i64p, i64p]
         L.orc_hetcor_skeleton.argtypes = [f32p, C.c_int, i32p, f32p, C.c_float, C.POINTER(C.c_int), C.c_int, i32p, i64p, i64p]
+        L.orc_pcstable_f64.restype = C.c_int
+        L.orc_pcstable_f64.argtypes = [f32p, C.c_int, i32p, C.c_double, C.c_double, C.c_int, i64p]
         L.orc_marker_phen_corr_pearson.argtypes = [u8p, f32p, C.c_size_t, C.c_size_t, C.c_size_t, f32p, f32p, f32p]
         L.orc_phen_corr_pearson.argtypes = [f32p, C.c_size_t, C.c_size_t, f32p]
         L.orc_marker_corr_npn.argtypes = [u8p, C.c_size_t, C.c_size_t, f32p]
@@ -155,6 +157,17 @@ def hetcor_skeleton(Cm, G, N, th: float, maxlevel: int, time_index) -> SkeletonR
     lvl = C.c_int(0)
     lib().orc_hetcor_skeleton(Cm, n, G, N, float(np.float32(th)), C.byref(lvl), int(maxlevel), ti, tests, subsets)
     return SkeletonResult(G, lvl.value, None, None, tests, subsets)
+
+
+def pcstable_f64(Cm: np.ndarray, num_samples: float, alpha: float, maxlevel: int) -> SkeletonResult:
+    """CPU baseline variant (not a parity oracle): PC-stable in double precision with pcalg::gaussCItest semantics,
+    sqrt(N - |S| - 3) |atanh r| <= qnorm(1 - alpha/2) removes the edge."""
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    n = Cm.shape[0]
+    G = np.zeros((n, n), np.int32)
+    tests = np.zeros(ML + 1, np.int64)
+    lvl = lib().orc_pcstable_f64(Cm, n, G, float(num_samples), float(alpha), int(maxlevel), tests)
+    return SkeletonResult(G, int(lvl), None, None, tests)
 
 
 # --------------------------------------------------------------------------
