@@ -10,9 +10,10 @@ not define them) are aliases of `cuskss` that insist on the flags that select th
 
 `sepselect` and `orient-v-structs` (ci-gwas.py:303-358, handlers :467-476) run this package's device-backed
 mirror of cusk_postprocessing/sepselect.py (ci-gwas_amd/sepselect.py) and write the same files.
-The rest of the downstream (merge-block-outputs, srfci, mvivw) is the reference's own
-code and consumes the files written here unchanged; after a merged run the reference's
-`reformat_cuskss_merged_output` is invoked when its package is importable.
+`merge-block-outputs` (ci-gwas.py:255-271, :459-464) and the post-step of a merged `cuskss` run (:452-456) use this
+package's mirror of the reference's merge module (ci-gwas_amd/merge.py), pinned by files the reference's own code
+wrote (tests/golden/merge).  The rest of the downstream (srfci, mvivw) is the reference's own code and consumes the
+files written here unchanged.
 """
 from __future__ import annotations
 
@@ -101,6 +102,14 @@ def _add_cuskss(sub, name, help_):
     p.set_defaults(func=cuskss, variant=name)
 
 
+def _add_merge(sub):
+    """ci-gwas.py:255-271"""
+    p = sub.add_parser("merge-block-outputs", help="Merge outputs of cusk for all blocks into single files")
+    p.add_argument("cusk_output_dir", metavar="cusk-output-dir", type=str, help="output directory of cusk")
+    p.add_argument("blockfile", type=str, help="file with genomic block definitions (output of ci-gwas block)")
+    p.set_defaults(func=merge_blocks)
+
+
 def _add_sepselect(sub):
     """ci-gwas.py:303-358"""
     for name, help_, func in (
@@ -129,6 +138,7 @@ def build_parser() -> argparse.ArgumentParser:
     _add_cuskss(sub, "cuskss", "Infer skeleton using summary statistic data (requires GPU)")
     _add_cuskss(sub, "cuskss-het", "cuskss with heterogeneous (polychoric/polyserial) correlations: needs --mxp-se/--pxp-se")
     _add_cuskss(sub, "cuskss-merged", "cuskss on the union of markers selected in all blocks: needs --marker-indices")
+    _add_merge(sub)
     _add_sepselect(sub)
     return parser
 
@@ -178,14 +188,19 @@ def cusk(args):
 def cuskss(args):
     subprocess.run(cuskss_argv(args), check=True)
     if args.marker_indices != "NULL":
-        # ci-gwas.py:452-456: the reference rewrites the merged output into its sparse merge format
-        try:
-            from cusk_postprocessing.merge_blocks import reformat_cuskss_merged_output
-        except ImportError:
-            sys.stderr.write("note: cusk_postprocessing (reference package) not importable; run the reference's "
-                             "reformat_cuskss_merged_output on the output directory\n")
-            return
+        # ci-gwas.py:452-456: the merged output is rewritten into the sparse merge format (needs
+        # <outdir>/merged_blocks.ixs, as in the reference)
+        from .merge import reformat_cuskss_merged_output
+
         reformat_cuskss_merged_output(cusk_dir=args.outdir).write_mm(basepath=f"{args.outdir}/cuskss_merged")
+
+
+def merge_blocks(args):
+    """ci-gwas.py:459-464"""
+    from .merge import merge_block_outputs
+
+    out_dir = args.cusk_output_dir if args.cusk_output_dir.endswith("/") else args.cusk_output_dir + "/"
+    merge_block_outputs(args.blockfile, out_dir).write_mm(f"{args.cusk_output_dir}/merged_blocks")
 
 
 def run_sepselect(args):

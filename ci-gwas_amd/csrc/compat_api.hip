@@ -67,3 +67,21 @@ extern "C" void hetcor_skeleton(float *C, int *P, int *G, float *N, float *Th, i
     cusk_dev_free(Cd);
     cusk_engine_destroy(e);
 }
+
+// corr_host.h:38-47, 92-103 with C linkage (ctypes, C hosts); the C++-linkage twins the reference's own callers bind to
+// live in compat_cxx.cpp
+extern "C" void cu_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                                            const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                                            const float *marker_std, float *marker_phen_corrs)
+{
+    cusk::compat_marker_phen_corr_pearson(marker_vals, phen_vals, num_markers, num_individuals, num_phen, marker_mean, marker_std,
+                                          marker_phen_corrs);
+}
+
+extern "C" void cu_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                                    const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                                    const float *marker_std, float *marker_corrs, float *marker_phen_corrs, float *phen_corrs)
+{
+    cusk::compat_corr_pearson_npn(marker_vals, phen_vals, num_markers, num_individuals, num_phen, marker_mean, marker_std,
+                                  marker_corrs, marker_phen_corrs, phen_corrs);
+}

@@ -1222,10 +1222,12 @@ cusk_engine *corr_engine()
 }
 }  // namespace
 
-extern "C" void cu_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals,
-                                            const size_t num_markers, const size_t num_individuals,
-                                            const size_t num_phen, const float *marker_mean, const float *marker_std,
-                                            float *marker_phen_corrs)
+namespace cusk {
+// bodies of the reference-named correlation entry points (host buffers in and out, engine per call); exported with C
+// linkage by compat_api.hip and with the reference's own C++ linkage by compat_cxx.cpp
+void compat_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                                     const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                                     const float *marker_std, float *marker_phen_corrs)
 {
     cusk_engine *e = corr_engine();
     if (corr_build_impl(e, marker_vals, phen_vals, num_markers, num_individuals, num_phen, marker_mean, marker_std, nullptr,
@@ -1237,10 +1239,9 @@ extern "C" void cu_marker_phen_corr_pearson(const unsigned char *marker_vals, co
     cusk_engine_destroy(e);
 }
 
-extern "C" void cu_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
-                                    const size_t num_individuals, const size_t num_phen, const float *marker_mean,
-                                    const float *marker_std, float *marker_corrs, float *marker_phen_corrs,
-                                    float *phen_corrs)
+void compat_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                             const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                             const float *marker_std, float *marker_corrs, float *marker_phen_corrs, float *phen_corrs)
 {
     cusk_engine *e = corr_engine();
     const size_t n = num_markers + num_phen;
@@ -1254,3 +1255,4 @@ extern "C" void cu_corr_pearson_npn(const unsigned char *marker_vals, const floa
     cusk_dev_free(Cd);
     cusk_engine_destroy(e);
 }
+}  // namespace cusk

@@ -146,4 +146,13 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
                     size_t p, const float *mean, const float *std, float *C_dev, float *mxp_host,
                     float *mxm_tri_host, float *pxp_tri_host);
 
+// reference-named correlation entry points (corr_build.hip); C linkage in compat_api.hip, C++ linkage in compat_cxx.cpp
+void compat_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                                     const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                                     const float *marker_std, float *marker_phen_corrs);
+void compat_corr_pearson_npn(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,
+                             const size_t num_individuals, const size_t num_phen, const float *marker_mean,
+                             const float *marker_std, float *marker_corrs, float *marker_phen_corrs, float *phen_corrs);
+double qnorm_host(double p);
+
 }  // namespace cusk

@@ -65,6 +65,8 @@ static double qnorm(double p)
     return x;
 }
 
+double qnorm_host(double p) { return qnorm(p); }
+
 void threshold_array_host(int n, float alpha, float *thr15)
 {
     const float half = 0.5f;

@@ -121,3 +121,23 @@ def test_prep_bed_subcommand():
 
     a = cli.build_parser().parse_args(["prep-bed", "data/chr"])
     assert a.bfiles == "data/chr" and a.func is cli.prep_bed
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/cusk/include/mps"), reason="needs the reference's headers (build container only)")
+def test_reference_headers_link_against_the_library_unchanged(tmp_path):
+    """A TU that includes the reference's <mps/corr_host.h> and <mps/cuPC_call_prep.h> links against libcusk_hip.so:
+    the C++-linkage names cu_corr_pearson_npn, cu_marker_phen_corr_pearson, threshold_array, hetcor_threshold,
+    std_normal_qnorm resolve with the reference's signatures, Skeleton / hetcor_skeleton with C linkage."""
+    import subprocess
+
+    lib_dir = os.path.join(ROOT, "ci-gwas_amd", "csrc")
+    exe = str(tmp_path / "link_ref")
+    r = subprocess.run(["g++", "-std=c++20", "-I/root/reference/cusk/include", os.path.join(ROOT, "tests", "link_ref", "link_ref_headers.cpp"),
+                        "-L" + lib_dir, "-lcusk_hip", "-Wl,-rpath," + lib_dir, "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    size, t0, het, q = out.stdout.split()[:4]
+    assert int(size) == 15 and abs(float(t0) - 0.0081045) < 1e-4  # the reference's own KAT (cupc_tests.cpp:10-15)
+    assert abs(float(het) - 3.8905919) < 1e-5 and abs(float(q) + 1.959964) < 1e-5
+    assert out.stdout.split()[4] == "4"
