@@ -85,6 +85,8 @@ struct cusk_engine
     std::vector<unsigned long long> binom_host;
     long long binom_rows = 0;  // rows of the device-resident binomial table
     hipEvent_t ev_cnt = nullptr;  // the level counters have reached the pinned mirror
+    hipEvent_t ev_cntl[cusk::kLevels];  // ... per level: the host follows the device at a distance (engine.hip)
+    long long item_cap_cur = 0;         // capacity (entries) of the per-class work-item buffers
     hipEvent_t ev_main[2] = {nullptr, nullptr};  // around the level-1 rows kernel alone
     hipEvent_t ev_run[2] = {nullptr, nullptr};
     hipEvent_t ev_k0[cusk::kLevels], ev_k1[cusk::kLevels], ev_l0[cusk::kLevels], ev_l1[cusk::kLevels];
@@ -101,6 +103,8 @@ struct cusk_engine
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
+    long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
+    int opt_lookahead = 2;               // levels the host may enqueue ahead of the counters it has seen
     long long opt_sep_ws_budget = 4ll << 30;  // HBM work space of cusk_sepselect_greedy for candidate lists beyond LDS
 
     // row-sharded sweep of ONE block over several engines: this engine runs the tests of rows

@@ -84,6 +84,9 @@ struct LevelPlan
     bool use_pair = false, use_fast = false, use_rows = false, filter_ok = true;
     size_t pair_lds = 0;
     bool redone = false;
+    bool known_items = false;  // nitems[] holds the level's real class counts (row-sharded runs wait for them)
+    int maxdeg_bound = 0;      // no row has more neighbours than this (newest maximum degree the host has seen)
+    int staged_classes = 0;
 };
 
 static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
@@ -159,13 +162,20 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     int level_out = (a.maxlevel < 0) ? 0 : last_level + 1;
     int levels_swept = 0;
     bool rows_timed = false;
+    // Gate of a level's finalisation and of the next level's plan: "the recheck queue held every uncertain test".  A
+    // level that is run (or redone) on the exact path has no queue: ~0.
+    unsigned long long qcap_gate[kLevels];
+    for (auto &q : qcap_gate) q = ~0ull;
+    long long &item_cap = e->item_cap_cur;
+    item_cap = std::max<long long>(item_cap, std::max<long long>(e->opt_item_cap, 1024));
 
     auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
         LevelPlan &pl = plan[l];
         SweepParams sp = pl.sp;
-        // The degree classes of a level are independent launches: the first non-empty class runs on the
-        // engine stream, the others on the auxiliary stream (many tiny rows next to a few hub rows fill the
-        // chip better together than one after the other); the streams join before the recheck pass.
+        // The degree classes of a level are independent launches: the first class runs on the engine stream, the
+        // others on the auxiliary stream (many tiny rows next to a few hub rows fill the chip better together than one
+        // after the other); the streams join before the recheck pass.  Every launch is persistent: the number of work
+        // items of its class is read on the device, so nothing here waits for the host (empty classes return at once).
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
@@ -174,8 +184,20 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             rows_timed = true;
             return CUSK_OK;
         }
+        // classes that can hold work at this level: a row of degree d belongs to the first class with d <= cap, and no
+        // degree exceeds the level-1 maximum
         int nonempty = 0;
-        for (int c = 0; c < kNumClasses; c++) nonempty += (pl.nitems[c] > 0);
+        bool may[kNumClasses];
+        for (int c = 0; c < kNumClasses; c++)
+        {
+            if (pl.known_items)
+                may[c] = pl.nitems[c] > 0;
+            else if (c < pl.staged_classes)
+                may[c] = (c == 0 ? 0 : kClassCap[c - 1] + 1) <= pl.maxdeg_bound;
+            else  // rows too large to stage all go to the last class
+                may[c] = (c == kNumClasses - 1) && (pl.staged_classes == 0 || pl.maxdeg_bound > kClassCap[pl.staged_classes - 1]);
+            nonempty += may[c];
+        }
         const bool fork = (nonempty > 1) && (e->opt_overlap != 0);
         if (fork)
         {
@@ -185,20 +207,22 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         bool first = true;
         for (int c = 0; c < kNumClasses; c++)
         {
-            if (pl.nitems[c] <= 0) continue;
+            if (!may[c]) continue;
             hipStream_t cs = (fork && !first) ? e->stream2 : s;
             first = false;
             sp.items = e->items[l & 1][c].as<int2>();
             sp.cap = kClassCap[c];
+            sp.cls = c;
+            sp.item_cap = item_cap;
             if (pl.use_pair && !exact_only)
-                CUSK_HIP(e, launch_pair(a.mode, sp, pl.nitems[c], pl.pair_lds, cs));
+                CUSK_HIP(e, launch_pair(a.mode, sp, pl.pair_lds, cs));
             else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
                      sweep_vec_lds_bytes(c) <= kLdsLimit && l < kVecMaxLevel)
-                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, pl.nitems[c], cs));
+                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, cs));
             else if (pl.use_fast && !exact_only)
-                CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, pl.nitems[c], cs));
+                CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, cs));
             else
-                CUSK_HIP(e, launch_sweep_exact(a.mode, het, l, sp, c, pl.nitems[c], cs));
+                CUSK_HIP(e, launch_sweep_exact(a.mode, het, l, sp, c, cs));
         }
         if (fork)
         {
@@ -211,25 +235,13 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     auto launch_level_finalize = [&](int l) -> int {
         if (a.mode != 0) return CUSK_OK;
         LevelPlan &pl = plan[l];
-        CUSK_HIP(e, launch_rec_scan(e->rowfound[l & 1].as<int>(), e->recoff[l & 1].as<int>(), n, dcnt + l, drec_base, l, s));
+        pl.fp.qcap = qcap_gate[l];
+        CUSK_HIP(e, launch_rec_scan(e->rowfound[l & 1].as<int>(), e->recoff[l & 1].as<int>(), n, dcnt + l, qcap_gate[l], drec_base,
+                                    l, s));
         // the winners' exact z (record_z) is off the critical path: it runs on the auxiliary stream while
         // the next level's compaction proceeds
         CUSK_HIP(e, launch_finalize(l, pl.fp, s, e->opt_overlap ? e->stream2 : s, e->ev_z));
         return CUSK_OK;
-    };
-    // a level whose recheck queue overflowed is redone on the exact path (everything the fast
-    // pass recorded is a certified verdict and stays valid); returns 1 when it had to
-    auto redo_if_overflowed = [&](int l) -> int {
-        if (sharded) return 0;  // sharded runs settle an overflow inside the level, before the exchange
-        if (l < 2 || !plan[l].use_fast || plan[l].redone) return 0;
-        if (e->hcnt[l].qcount <= (unsigned long long)e->opt_queue_cap) return 0;
-        plan[l].redone = true;
-        local.exact_fallbacks++;
-        int rc = launch_level_sweeps(l, true);
-        if (rc != CUSK_OK) return -rc;
-        rc = launch_level_finalize(l);
-        if (rc != CUSK_OK) return -rc;
-        return 1;
     };
 
     // row-sharded runs: join the engines' selection state after a level's sweep (unsigned MIN), then derive what the
@@ -244,6 +256,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             {
                 pl.redone = true;
                 local.exact_fallbacks++;
+                qcap_gate[l] = ~0ull;
                 const int rc = launch_level_sweeps(l, true);
                 if (rc != CUSK_OK) return rc;
             }
@@ -283,59 +296,78 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
 
     if (last_level >= 1) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
 
-    for (int l = 1; l <= last_level; l++)
+    // which classes can be staged in LDS in this mode
+    int staged_classes = 0;
+    while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit) staged_classes++;
+    const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+    // The host enqueues levels AHEAD of the device: every kernel of a level checks the level's gate on the device
+    // (LevelCounters::active, set by the level's plan), sweeps are persistent launches that read their work-item counts
+    // on the device, so no launch needs a number from the host.  The host only follows `lookahead` levels behind (it
+    // waits for the counters of level l - lookahead before it enqueues level l + 1) to stop enqueuing once the loop has
+    // ended; that wait overlaps the device's work on the levels in between.  Row-sharded runs call back into the host
+    // every level and follow at distance 0.
+    const int lookahead = sharded ? 0 : std::max(0, e->opt_lookahead);
+    int maxdeg1 = 0;
+    int start = 1;   // first level to enqueue in this pass
+    int redo = 0;    // level whose recheck queue overflowed: its sweeps run again on the exact path before `start`
+    bool first_pass = true;
+
+    for (;;)
     {
-        const int cs = l & 1;
-        CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
-        bool rebuilt = false;
-        for (;;)
+        if (redo > 0)
+        {  // everything the fast pass recorded is a certified verdict and stays valid
+            plan[redo].redone = true;
+            local.exact_fallbacks++;
+            qcap_gate[redo] = ~0ull;
+            int rc = launch_level_sweeps(redo, true);
+            if (rc != CUSK_OK) return rc;
+            rc = launch_level_finalize(redo);
+            if (rc != CUSK_OK) return rc;
+            CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
+            redo = 0;
+        }
+        int enq_last = start - 1;
+        for (int l = start; l <= last_level; l++)
         {
-            // which classes can be staged in LDS in this mode
-            int staged_classes = 0;
-            while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit)
-                staged_classes++;
-            const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+            const int cs = l & 1;
+            {  // follow the device at a distance: has the loop ended `lookahead` levels ago?
+                const int k = l - 1 - lookahead;
+                if (k >= start)
+                {
+                    CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[k]));
+                    if (!e->hcnt[k].active) break;
+                }
+            }
+            CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
             LevelPlan &pl = plan[l];
             pl.redone = false;
-            const bool first_build = (l == 1 && !rebuilt);
-            if (rebuilt)  // the plan accumulates its totals with atomics: start from zero again
-                CUSK_HIP(e, hipMemsetAsync(dcnt + l, 0, sizeof(LevelCounters), s));
-            // 1. the plan of the level from the degrees alone; its counters start their way to the host at once ...
-            //    (level 1 is planned for the generic kernels: whether the matrix is symmetric is only known with
-            //    this read-back, and the row-streaming kernel does not use work items)
+            pl.known_items = false;
+            const bool first_build = (l == 1 && first_pass);
+            const LevelCounters *prev = (l >= 2) ? dcnt + (l - 1) : nullptr;
+            const unsigned long long prev_q = (l >= 2) ? qcap_gate[l - 1] : ~0ull;
+            // 1. the plan of the level from the degrees alone (level 1 is planned for the generic kernels first: whether
+            //    the matrix is symmetric is only known with the first read-back, and the row-streaming kernel does not
+            //    use work items)
             bool pair_items = (l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows;
             CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
-                                    e->binom.as<unsigned long long>(), chunk,
-                                    staged_classes, pair_items ? 1 : 0, dcnt + l, e->shard_rank, e->shard_world, s));
+                                    e->binom.as<unsigned long long>(), chunk, staged_classes, pair_items ? 1 : 0, dcnt + l, prev,
+                                    prev_q, item_cap, e->shard_rank, e->shard_world, s));
             if (first_build) CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
             CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
-            CUSK_HIP(e, hipEventRecord(e->ev_cnt, s));
-            auto build_lists = [&]() -> int {
-                pl.use_fast = (e->opt_fast != 0) && (l >= 2);
-                CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
-                                            (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
-                                            a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words,
-                                            pl.use_rows ? e->wpre.as<int>() : nullptr, s));
-                return CUSK_OK;
-            };
-            // 2. ... while the device already compacts the neighbour lists (nothing there depends on the host),
-            if (!first_build)
-            {
-                int rc = build_lists();
-                if (rc != CUSK_OK) return rc;
-            }
-            // 3. the level's one host round trip: wait for the counters only, not for the stream
-            CUSK_HIP(e, hipEventSynchronize(e->ev_cnt));
+            CUSK_HIP(e, hipEventRecord(e->ev_cntl[l], s));
             if (first_build)
             {
-                // sizes of the CSR arrays and of the binomial table come from the level-1 degrees
+                // the run's one mandatory round trip: sizes of the CSR arrays and of the binomial table come from the
+                // level-1 degrees
+                CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[l]));
                 symmetric = (*e->hflag == 0) || (e->opt_assume_symmetric != 0);
                 cap_edges = std::max<long long>(e->hcnt[1].total_edges, 1);
-                const int maxdeg1 = e->hcnt[1].maxdeg;
+                maxdeg1 = e->hcnt[1].maxdeg;
                 for (int k = 0; k < 2; k++)
                 {
                     CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
                     if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
+                    for (int c = 0; c < kNumClasses; c++) CUSK_HIP(e, e->items[k][c].ensure(sizeof(int2) * (size_t)item_cap));
                 }
                 CUSK_HIP(e, e->rv.ensure(sizeof(float) * (size_t)cap_edges));
                 CUSK_HIP(e, e->rpos.ensure(sizeof(int) * 4 * (size_t)cap_edges));
@@ -349,6 +381,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     CUSK_HIP(e, e->rec_s.ensure(sizeof(int) * kML * (size_t)cap_edges));
                 }
                 e->rec_cap = cap_edges;
+                CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
                 // binomial table C(a, b), a <= max degree: kept on the device across runs
                 if ((long long)maxdeg1 >= e->binom_rows)
                 {
@@ -363,142 +396,182 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     e->binom_rows = rows;
                 }
                 // level 1 on a symmetric matrix with a single threshold: row-streaming kernel (or the pair kernel)
-                pl.pair_lds = (size_t)e->hcnt[1].maxdeg * 20 + 16;
+                pl.pair_lds = (size_t)maxdeg1 * 20 + 16;
                 pl.use_pair = !het && symmetric && (e->opt_pair != 0) && pl.pair_lds <= 64 * 1024;
                 pl.use_rows = !het && symmetric && (e->opt_pair != 0) && (e->opt_rows != 0);
                 if (pl.use_rows) CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
                 if (pl.use_pair && !pl.use_rows)
                 {  // the pair kernel counts its work items differently: plan again (option rows = 0 only)
-                    rebuilt = true;
-                    continue;
+                    CUSK_HIP(e, hipMemsetAsync(dcnt + l, 0, sizeof(LevelCounters), s));
+                    CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
+                                            e->binom.as<unsigned long long>(), chunk, staged_classes, 1, dcnt + l, prev, prev_q,
+                                            item_cap, e->shard_rank, e->shard_world, s));
+                    CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
+                    CUSK_HIP(e, hipEventRecord(e->ev_cntl[l], s));
                 }
-                int rc = build_lists();
+                first_pass = false;
+            }
+            if (sharded)
+            {  // the exchange below is a collective: every engine must know now whether the level runs
+                CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[l]));
+                if (!e->hcnt[l].active) break;
+                for (int c = 0; c < kNumClasses; c++) pl.nitems[c] = e->hcnt[l].class_items[c];
+                pl.known_items = true;
+            }
+            {  // degrees only shrink: the newest level whose counters have arrived bounds every later one
+                pl.maxdeg_bound = maxdeg1;
+                const int k = l - 1 - lookahead;
+                if (k >= 1 && e->hcnt[k].active) pl.maxdeg_bound = std::min(maxdeg1, e->hcnt[k].maxdeg);
+                pl.staged_classes = staged_classes;
+            }
+            pl.use_fast = (e->opt_fast != 0) && (l >= 2);
+            // 2. neighbour lists and work items (no host dependency)
+            CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
+                                        (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
+                                        a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words,
+                                        pl.use_rows ? e->wpre.as<int>() : nullptr, dcnt + l, s));
+            if (!pl.use_rows)
+            {
+                int2 *iptr[kNumClasses];
+                for (int c = 0; c < kNumClasses; c++) iptr[c] = e->items[cs][c].as<int2>();
+                CUSK_HIP(e, launch_fill_items(e->rowinfo[cs].as<RowInfo>(), n, iptr, item_cap, dcnt + l, s));
+            }
+
+            SweepParams &sp = pl.sp;
+            sp.C = a.C;
+            sp.Ness = a.Ness;
+            sp.n = n;
+            sp.level = l;
+            sp.off = e->off[cs].as<int>();
+            sp.nbr = e->nbr[cs].as<int>();
+            sp.best = e->best[cs].as<unsigned long long>();
+            sp.rowfound = e->rowfound[cs].as<int>();
+            sp.adj = e->adj.as<unsigned long long>();
+            sp.deg = e->deg.as<int>();
+            sp.words = words;
+            sp.items = nullptr;
+            sp.binom = e->binom.as<unsigned long long>();
+            sp.time_index = e->ti.as<int>();
+            sp.chunk = chunk;
+            sp.cap = 0;
+            sp.cls = 0;
+            sp.item_cap = item_cap;
+            sp.cnt = dcnt + l;
+            sp.slots = dslots + (size_t)l * kCounterSlots * 4;
+            if (a.mode == 0)
+                sp.th = a.Th[l];
+            else if (het)
+                sp.th = a.Th[0];
+            else
+                sp.th = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
+            {
+                const double tq = std::tanh((double)sp.th);
+                sp.t2 = (float)(tq * tq);
+                // The guard band of the filter (ci_fast.h) is relative; the fp32 Fisher z of the exact path carries an
+                // absolute error of ~1e-7.  Below this threshold the margin between the two gets thin, so such levels
+                // (N beyond ~4 million samples at alpha 1e-4) run entirely on the exact arithmetic.
+                pl.filter_ok = (sp.th >= kThMinFilter);
+                if (!pl.filter_ok) pl.use_fast = false;
+            }
+            sp.queue = nullptr;
+            sp.qcap = 0;
+            qcap_gate[l] = ~0ull;
+            if (pl.use_fast)
+            {
+                sp.queue = e->queue.as<RecheckEntry>();
+                sp.qcap = (unsigned long long)e->opt_queue_cap;
+                qcap_gate[l] = sp.qcap;
+            }
+            FinalizeParams &fp = pl.fp;
+            fp.C = a.C;
+            fp.n = n;
+            fp.off = sp.off;
+            fp.nbr = sp.nbr;
+            fp.best = sp.best;
+            fp.recoff = e->recoff[cs].as<int>();
+            fp.rec_base = drec_base;
+            fp.level = l;
+            fp.adj = sp.adj;
+            fp.deg = sp.deg;
+            fp.words = words;
+            fp.binom = sp.binom;
+            fp.rec_x = e->rec_x.as<int>();
+            fp.rec_y = e->rec_y.as<int>();
+            fp.rec_l = e->rec_l.as<int>();
+            fp.rec_s = e->rec_s.as<int>();
+            fp.rec_cap = e->rec_cap;
+            fp.rec_z = e->rec_z.as<float>();
+            fp.meta = pl.use_rows ? e->rpos.as<int4>() : nullptr;
+            fp.cnt = dcnt + l;
+            fp.qcap = qcap_gate[l];
+
+            CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
+            int rc = launch_level_sweeps(l, false);
+            if (rc != CUSK_OK) return rc;
+            CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
+            if (sharded)
+            {
+                rc = shard_join(l);
                 if (rc != CUSK_OK) return rc;
             }
-            // did the previous level's recheck queue overflow?  then redo it and rebuild this level
-            const int redo = redo_if_overflowed(l - 1);
-            if (redo < 0) return -redo;
-            if (redo == 1)
-            {
-                rebuilt = true;
-                continue;
-            }
-            break;
-        }
-        const LevelCounters &hc = e->hcnt[l];
-        local.max_degree[l] = hc.maxdeg;
-        local.edges[l] = hc.total_edges;
-        if (hc.maxdeg - 1 < l)
-        {  // cuPC-S.cu:154-159
-            level_out = l - 1;
-            break;
-        }
-        if (hc.overflow)
-            return fail(e, CUSK_ERR_OVERFLOW,
-                        "C(degree, level) exceeds 2^62 at level " + std::to_string(l) + " (max degree " +
-                            std::to_string(hc.maxdeg) + ")");
-        LevelPlan &pl = plan[l];
-        int2 *iptr[kNumClasses];
-        for (int c = 0; c < kNumClasses; c++)
-        {
-            pl.nitems[c] = hc.class_items[c];
-            CUSK_HIP(e, e->items[cs][c].ensure(sizeof(int2) * (size_t)std::max<long long>(pl.nitems[c], 1)));
-            iptr[c] = e->items[cs][c].as<int2>();
-        }
-        CUSK_HIP(e, launch_fill_items(e->rowinfo[cs].as<RowInfo>(), n, iptr, s));
-
-        SweepParams &sp = pl.sp;
-        sp.C = a.C;
-        sp.Ness = a.Ness;
-        sp.n = n;
-        sp.level = l;
-        sp.off = e->off[cs].as<int>();
-        sp.nbr = e->nbr[cs].as<int>();
-        sp.best = e->best[cs].as<unsigned long long>();
-        sp.rowfound = e->rowfound[cs].as<int>();
-        sp.adj = e->adj.as<unsigned long long>();
-        sp.deg = e->deg.as<int>();
-        sp.words = words;
-        sp.items = nullptr;
-        sp.binom = e->binom.as<unsigned long long>();
-        sp.time_index = e->ti.as<int>();
-        sp.chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
-        sp.cap = 0;
-        sp.cnt = dcnt + l;
-        sp.slots = dslots + (size_t)l * kCounterSlots * 4;
-        if (a.mode == 0)
-            sp.th = a.Th[l];
-        else if (het)
-            sp.th = a.Th[0];
-        else
-            sp.th = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
-        {
-            const double tq = std::tanh((double)sp.th);
-            sp.t2 = (float)(tq * tq);
-            // The guard band of the filter (ci_fast.h) is relative; the fp32 Fisher z of the exact path carries an
-            // absolute error of ~1e-7.  Below this threshold the margin between the two gets thin, so such levels
-            // (N beyond ~4 million samples at alpha 1e-4) run entirely on the exact arithmetic.
-            pl.filter_ok = (sp.th >= kThMinFilter);
-            if (!pl.filter_ok) pl.use_fast = false;
-        }
-        sp.queue = nullptr;
-        sp.qcap = 0;
-        if (pl.use_fast)
-        {
-            CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
-            sp.queue = e->queue.as<RecheckEntry>();
-            sp.qcap = (unsigned long long)e->opt_queue_cap;
-        }
-        FinalizeParams &fp = pl.fp;
-        fp.C = a.C;
-        fp.n = n;
-        fp.off = sp.off;
-        fp.nbr = sp.nbr;
-        fp.best = sp.best;
-        fp.recoff = e->recoff[cs].as<int>();
-        fp.rec_base = drec_base;
-        fp.level = l;
-        fp.adj = sp.adj;
-        fp.deg = sp.deg;
-        fp.words = words;
-        fp.binom = sp.binom;
-        fp.rec_x = e->rec_x.as<int>();
-        fp.rec_y = e->rec_y.as<int>();
-        fp.rec_l = e->rec_l.as<int>();
-        fp.rec_s = e->rec_s.as<int>();
-        fp.rec_cap = e->rec_cap;
-        fp.rec_z = e->rec_z.as<float>();
-        fp.meta = pl.use_rows ? e->rpos.as<int4>() : nullptr;
-
-        CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
-        int rc = launch_level_sweeps(l, false);
-        if (rc != CUSK_OK) return rc;
-        CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
-        if (sharded)
-        {
-            rc = shard_join(l);
+            rc = launch_level_finalize(l);
             if (rc != CUSK_OK) return rc;
+            CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
+            enq_last = l;
         }
-        rc = launch_level_finalize(l);
-        if (rc != CUSK_OK) return rc;
-        CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
-        levels_swept = l;
-        local.levels_run++;
-    }
 
-    // final read-back (and a late overflow check for the last level that ran)
-    for (;;)
-    {
+        // read-back of the whole control block, then: did every enqueued level run to completion?
         CUSK_HIP(e, hipEventRecord(e->ev_join, e->stream2));
         CUSK_HIP(e, hipStreamWaitEvent(s, e->ev_join, 0));
         // counters, slots and record bases in one copy (hcnt, hslots, hrec_base point into the pinned mirror)
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, ctl, ctl_sym, hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipEventRecord(e->ev_run[1], s));
         CUSK_HIP(e, hipStreamSynchronize(s));
-        const int redo = redo_if_overflowed(levels_swept);
-        if (redo < 0) return -redo;
-        if (redo == 0) break;
+        int ended = 0;  // first level whose gate stayed closed
+        for (int l = 1; l <= enq_last && !ended; l++)
+            if (!e->hcnt[l].active) ended = l;
+        const int last_ran = ended ? ended - 1 : enq_last;
+        // a recheck queue that overflowed: that level was not finalised and nothing after it ran
+        if (!sharded && last_ran >= 2 && plan[last_ran].use_fast && !plan[last_ran].redone &&
+            e->hcnt[last_ran].qcount > (unsigned long long)e->opt_queue_cap)
+        {
+            redo = last_ran;
+            start = last_ran + 1;
+        }
+        else if (ended && e->hcnt[ended].overflow)
+            return fail(e, CUSK_ERR_OVERFLOW,
+                        "C(degree, level) exceeds 2^62 at level " + std::to_string(ended) + " (max degree " +
+                            std::to_string(e->hcnt[ended].maxdeg) + ")");
+        else if (ended && e->hcnt[ended].item_overflow)
+        {  // more work items than the buffers hold: grow them and take the level up again
+            long long need = item_cap;
+            for (int c = 0; c < kNumClasses; c++) need = std::max(need, e->hcnt[ended].class_items[c]);
+            item_cap = need + need / 4;
+            for (int k = 0; k < 2; k++)
+                for (int c = 0; c < kNumClasses; c++) CUSK_HIP(e, e->items[k][c].ensure(sizeof(int2) * (size_t)item_cap));
+            start = ended;
+        }
+        else
+        {
+            levels_swept = last_ran;
+            if (ended) level_out = ended - 1;  // cuPC-S.cu:154-159
+            break;
+        }
+        // resume: the counters of the levels that are enqueued again start from zero
+        if (start <= last_level)
+        {
+            CUSK_HIP(e, hipMemsetAsync(dcnt + start, 0, sizeof(LevelCounters) * (size_t)(kLevels - start), s));
+            CUSK_HIP(e, hipMemsetAsync(dslots + (size_t)start * kCounterSlots * 4, 0,
+                                       sizeof(unsigned long long) * (size_t)(kLevels - start) * kCounterSlots * 4, s));
+        }
     }
+    // degrees and edge counts at the start of every level that was planned (the one at which the loop ended included)
+    for (int l = 1; l <= std::min(levels_swept + 1, last_level); l++)
+    {
+        local.max_degree[l] = e->hcnt[l].maxdeg;
+        local.edges[l] = e->hcnt[l].total_edges;
+    }
+    local.levels_run += levels_swept;
     float ms = 0.0f;
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[0], e->ev_l1[0]));
     local.kernel_ms[0] = local.level_ms[0] = ms;
@@ -555,7 +628,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     if (hipSetDevice(device) != hipSuccess) return CUSK_ERR_HIP;
     cusk_engine *e = new cusk_engine();
     e->device = device;
-    for (int l = 0; l < kLevels; l++) e->ev_k0[l] = e->ev_k1[l] = e->ev_l0[l] = e->ev_l1[l] = nullptr;
+    for (int l = 0; l < kLevels; l++) e->ev_k0[l] = e->ev_k1[l] = e->ev_l0[l] = e->ev_l1[l] = e->ev_cntl[l] = nullptr;
     bool ok = true;
     if (stream)
     {
@@ -590,6 +663,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     {
         ok = ok && hipEventCreate(&e->ev_k0[l]) == hipSuccess && hipEventCreate(&e->ev_k1[l]) == hipSuccess;
         ok = ok && hipEventCreate(&e->ev_l0[l]) == hipSuccess && hipEventCreate(&e->ev_l1[l]) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&e->ev_cntl[l], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok)
     {
@@ -625,7 +699,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     for (auto &ev : e->ev_corr)
         if (ev) (void)hipEventDestroy(ev);
     for (int l = 0; l < kLevels; l++)
-        for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
+        for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l], e->ev_cntl[l]})
             if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
@@ -661,6 +735,13 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)
         e->opt_chunk = value;
+    else if (k == "item_capacity" && value > 0)
+    {
+        e->opt_item_cap = value;
+        e->item_cap_cur = 0;  // takes effect with the next run (buffers only ever grow)
+    }
+    else if (k == "lookahead" && value >= 0)
+        e->opt_lookahead = (int)value;
     else if (k == "sepselect_ws_bytes" && value > 0)
         e->opt_sep_ws_budget = value;
     else

@@ -32,6 +32,14 @@ struct LevelCounters
     long long class_items[kNumClasses];
     unsigned long long qcount;     // tests queued for the exact path (may exceed the capacity)
     unsigned long long rec_total;  // separating-set records produced by this level
+    // The level's gate, decided on the device so that the host can enqueue levels ahead of their counters: set by the
+    // last workgroup of plan_kernel to "the previous level ran to completion (its recheck queue did not overflow), a row
+    // with more than `level` neighbours exists (cuPC-S.cu:154-159), no binomial overflowed, the work items fit their
+    // buffers".  Every other kernel of the level returns at once when it is 0.
+    int active;
+    int item_overflow;         // a degree class has more work items than its buffer holds (host grows it and resumes)
+    unsigned int done_blocks;  // plan_kernel workgroups that have finished (ticket of the last one)
+    int pad;
 };
 
 struct SweepParams
@@ -54,6 +62,8 @@ struct SweepParams
     float t2;               // tanh(th)^2 for the fixed-threshold fast filter
     unsigned long long chunk;
     int cap;  // class capacity (LDS carve), ignored when !STAGED
+    int cls;  // degree class of this launch: its work-item count is cnt->class_items[cls] (read on the device)
+    long long item_cap;         // capacity of the class's work-item buffer
     LevelCounters *cnt;         // this level's counters
     unsigned long long *slots;  // this level's kCounterSlots x 4 spread counters: tests, subsets, removed, violations
     RecheckEntry *queue;
@@ -78,6 +88,8 @@ struct FinalizeParams
     long long rec_cap;
     float *rec_z;
     const int4 *meta;  // level 1 (row-streaming kernel ran): per CSR slot {Y, position of X in Y's list, off[Y], deg[Y]}
+    const LevelCounters *cnt;  // this level's counters (gate)
+    unsigned long long qcap;   // capacity of the level's recheck queue: an overflowed level is not finalised (it is redone)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -101,6 +113,19 @@ __host__ __device__ inline LdsLayout lds_layout(int cap, bool het)
 }
 
 #if defined(__HIPCC__)
+// work items of this launch's degree class; 0 when the level's gate is closed
+__device__ __forceinline__ long long level_items(const SweepParams &p)
+{
+    if (!p.cnt->active) return 0;
+    const long long c = p.cnt->class_items[p.cls];
+    return c < p.item_cap ? c : p.item_cap;
+}
+// a level is finalised when it ran and its recheck queue held every uncertain test
+__device__ __forceinline__ bool level_complete(const LevelCounters *cnt, unsigned long long qcap)
+{
+    return cnt->active && cnt->qcount <= qcap;
+}
+
 // mean_ess of hetcor-cuPC-S.cu:3068-3088: entries truncated to int (v_cvt_i32_f32
 // saturates and maps NaN to 0, as the reference's GPU does)
 __device__ __forceinline__ float ess_term(float e) { return (float)(int)e; }
@@ -145,36 +170,40 @@ __device__ __forceinline__ bool clear_edge(unsigned long long *adj, int *deg, in
 
 // ---- launchers (one translation unit each) ----
 // sweep_exact.hip
-hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st);
+hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, hipStream_t st);
 hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st);
 hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z);
 // sweep_fast.hip
-hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
-                             hipStream_t st);
+hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st);
 // sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
-hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st);
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, hipStream_t st);
+// workgroups of a persistent sweep launch: what the chip holds at once for this kernel (occupancy x CUs), cached
+unsigned persistent_grid(const void *kernel, int threads, size_t lds);
 size_t sweep_vec_lds_bytes(int cls);
 // sweep_level.hip: level 0, compaction, level-1 pair kernel, result expansion
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st);
 hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int *wpre, hipStream_t st);
+                           int n, int words, int *wpre, const LevelCounters *cnt, hipStream_t st);
+// cnt = counters of level L; prev = counters of level L-1 (nullptr at level 1) with its recheck-queue capacity
 hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt,
+                       const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap, int shard_rank,
                        int shard_world, hipStream_t st);
 // rowfound[row] = slots of the row whose best is set (after a cross-engine MIN of best, row-sharded runs)
 hipError_t launch_count_found(const int *off, const unsigned long long *best, int *rowfound, int n, hipStream_t st);
-hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st);
+hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, long long item_cap, const LevelCounters *cnt,
+                             hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
                                  hipStream_t st);
-hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
-                           hipStream_t st);
+hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, unsigned long long qcap,
+                           long long *rec_base, int level, hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
                               int shard_world, bool defer_count, hipStream_t st);
 hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st);
-hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st);
+hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);
 hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,

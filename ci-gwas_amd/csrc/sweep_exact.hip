@@ -6,6 +6,8 @@
 // off, for level 1 on asymmetric / heterogeneous-ESS inputs, and as the fallback when the
 // recheck queue overflows.  recheck_kernel evaluates the tests the fast filter could not
 // certify; finalize_kernel turns the selected ranks into sparse separating-set records.
+#include <algorithm>
+
 #include "ci_exact.h"
 #include "sweep_stage.h"
 
@@ -16,14 +18,19 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_cnt[4];
-    const int2 item = p.items[blockIdx.x];
-    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    unsigned long long ntests = 0, nsub = 0, nrem = 0;
+    // persistent launch: the class's work items are counted on the device (sweep_common.h: level_items)
+    const long long nitems = level_items(p);
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
+    {
+    if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the staged copy
+    const int2 item = p.items[it];
+    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
     rv.stage();
     const int d = rv.d;
     const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + L], item.y, p.chunk);
 
-    unsigned long long ntests = 0, nsub = 0, nrem = 0;
     if (rr.lo < rr.hi)
     {
         int idx[L];
@@ -79,13 +86,14 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
             if (!next_comb<L>(idx, d)) break;
         }
     }
+    }  // work items
+    __syncthreads();
     flush_counters(s_cnt, p.slots, ntests, nsub, nrem, 0ull);
 }
 
 template <int L, int MODE, bool HET>
-static hipError_t launch_exact_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+static hipError_t launch_exact_L(const SweepParams &p, int cls, hipStream_t st)
 {
-    if (nitems <= 0) return hipSuccess;
     if (cls < kNumClasses - 1)
     {
         const size_t lds = lds_layout(kClassCap[cls], HET).total;
@@ -96,26 +104,31 @@ static hipError_t launch_exact_L(const SweepParams &p, int cls, long long nitems
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
     }
     else
     {
-        hipLaunchKernelGGL((sweep_kernel<L, MODE, HET, false>), dim3((unsigned)nitems), dim3(kThreads), 16, st, p);
+        auto kfn = sweep_kernel<L, MODE, HET, false>;
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, 16),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), 16, st, p);
     }
     return hipGetLastError();
 }
 
 #define CUSK_FOR_LEVELS(M) M(1) M(2) M(3) M(4) M(5) M(6) M(7) M(8) M(9) M(10) M(11) M(12) M(13) M(14)
 
-hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st)
+hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, hipStream_t st)
 {
     switch (L)
     {
 #define CUSK_CASE(LL)                                                               \
     case LL:                                                                        \
-        if (mode == 0) return launch_exact_L<LL, 0, false>(p, cls, nitems, st);     \
-        return het ? launch_exact_L<LL, 1, true>(p, cls, nitems, st)                \
-                   : launch_exact_L<LL, 1, false>(p, cls, nitems, st);
+        if (mode == 0) return launch_exact_L<LL, 0, false>(p, cls, st);             \
+        return het ? launch_exact_L<LL, 1, true>(p, cls, st)                        \
+                   : launch_exact_L<LL, 1, false>(p, cls, st);
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE
     }
@@ -241,7 +254,7 @@ __global__ void gather_records_kernel(FinalizeParams p)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= p.n) return;
+    if (row >= p.n || !level_complete(p.cnt, p.qcap)) return;
     const int o0 = p.off[row];
     const int d = p.off[row + 1] - o0;
     long long next = p.rec_base[p.level] + p.recoff[row];
@@ -311,6 +324,7 @@ template <int L>
 __global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams p)
 {
     extern __shared__ __attribute__((aligned(16))) float ws_lds[];
+    if (!level_complete(p.cnt, p.qcap)) return;
     const long long first = p.rec_base[p.level], count = p.rec_base[p.level + 1] - first;
     const int n = p.n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)

@@ -4,6 +4,8 @@
 // sweep_kernel; every test is first judged by the filter, certified verdicts are applied at
 // once and the uncertain remainder is queued for recheck_kernel (exact path).  VALIDATE also
 // runs the exact arithmetic on every certified verdict and counts contradictions.
+#include <algorithm>
+
 #include "ci_exact.h"
 #include "ci_fast.h"
 #include "sweep_stage.h"
@@ -19,14 +21,19 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     static_assert(L >= 2, "level 1 has its own kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_cnt[4];
-    const int2 item = p.items[blockIdx.x];
-    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
     if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
+    // persistent launch: the class's work items are counted on the device (sweep_common.h: level_items)
+    const long long nitems = level_items(p);
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
+    {
+    if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the staged copy
+    const int2 item = p.items[it];
+    RowView<MODE, HET, STAGED> rv(p, item.x, smem);
     rv.stage();
     const int d = rv.d;
     const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + L], item.y, p.chunk);
 
-    unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
     if (rr.lo < rr.hi)
     {
         int idx[L];
@@ -140,13 +147,14 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
             if (changed < 0) break;
         }
     }
+    }  // work items
+    __syncthreads();
     flush_counters(s_cnt, p.slots, ntests, nsub, nrem, nbad);
 }
 
 template <int L, int MODE, bool HET, bool VALIDATE>
-static hipError_t launch_fast_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+static hipError_t launch_fast_L(const SweepParams &p, int cls, hipStream_t st)
 {
-    if (nitems <= 0) return hipSuccess;
     if (cls < kNumClasses - 1)
     {
         const size_t lds = lds_layout(kClassCap[cls], HET).total;
@@ -157,36 +165,38 @@ static hipError_t launch_fast_L(const SweepParams &p, int cls, long long nitems,
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
     }
     else
     {
-        hipLaunchKernelGGL((sweep_fast_kernel<L, MODE, HET, false, VALIDATE>), dim3((unsigned)nitems), dim3(kThreads), 16, st,
-                           p);
+        auto kfn = sweep_fast_kernel<L, MODE, HET, false, VALIDATE>;
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, 16),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), 16, st, p);
     }
     return hipGetLastError();
 }
 
 template <int L>
-static hipError_t launch_fast_level(int mode, bool het, bool validate, const SweepParams &p, int cls, long long nitems,
-                                    hipStream_t st)
+static hipError_t launch_fast_level(int mode, bool het, bool validate, const SweepParams &p, int cls, hipStream_t st)
 {
     if (validate)
     {
-        if (mode == 0) return launch_fast_L<L, 0, false, true>(p, cls, nitems, st);
-        return het ? launch_fast_L<L, 1, true, true>(p, cls, nitems, st) : launch_fast_L<L, 1, false, true>(p, cls, nitems, st);
+        if (mode == 0) return launch_fast_L<L, 0, false, true>(p, cls, st);
+        return het ? launch_fast_L<L, 1, true, true>(p, cls, st) : launch_fast_L<L, 1, false, true>(p, cls, st);
     }
-    if (mode == 0) return launch_fast_L<L, 0, false, false>(p, cls, nitems, st);
-    return het ? launch_fast_L<L, 1, true, false>(p, cls, nitems, st) : launch_fast_L<L, 1, false, false>(p, cls, nitems, st);
+    if (mode == 0) return launch_fast_L<L, 0, false, false>(p, cls, st);
+    return het ? launch_fast_L<L, 1, true, false>(p, cls, st) : launch_fast_L<L, 1, false, false>(p, cls, st);
 }
 
-hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, long long nitems,
-                             hipStream_t st)
+hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st)
 {
     switch (L)
     {
 #define CUSK_CASE(LL) \
-    case LL: return launch_fast_level<LL>(mode, het, validate, p, cls, nitems, st);
+    case LL: return launch_fast_level<LL>(mode, het, validate, p, cls, st);
         CUSK_CASE(2)
         CUSK_CASE(3)
         CUSK_CASE(4)

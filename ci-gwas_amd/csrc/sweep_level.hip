@@ -4,6 +4,8 @@
 // :486-582 (cal_Indepl1) and their hetcor twins (src/hetcor-cuPC-S.cu:343-486).
 #include <algorithm>
 #include <cmath>
+#include <map>
+#include <mutex>
 #include <type_traits>
 
 #include "ci_exact.h"
@@ -311,11 +313,12 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
 
 // one wave per row: ascending neighbour indices, reset of the row's selection state
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
-                                unsigned long long *best, int *rowfound, int n, int words, int *wpre)
+                                unsigned long long *best, int *rowfound, int n, int words, int *wpre,
+                                const LevelCounters *cnt)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (row >= n || !cnt->active) return;
     const int o0 = off[row];
     int run = 0;
     for (int w0 = 0; w0 < words; w0 += 64)
@@ -346,9 +349,9 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
 }
 
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int *wpre, hipStream_t st)
+                           int n, int words, int *wpre, const LevelCounters *cnt, hipStream_t st)
 {
-    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, wpre);
+    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, wpre, cnt);
     return hipGetLastError();
 }
 
@@ -397,12 +400,17 @@ __device__ __forceinline__ long long prefix_256(const int *__restrict__ in, int 
 // irrelevant: items of a class are independent).  class_items[] ends up holding the class totals.
 __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, int *off, RowInfo *rowinfo, int n, int L,
                                                      const unsigned long long *__restrict__ binom, unsigned long long chunk,
-                                                     int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
-                                                     int shard_world)
+                                                     int staged_classes, int pair_mode, LevelCounters *cnt,
+                                                     const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap,
+                                                     int shard_rank, int shard_world)
 {
     __shared__ int s_wave[kNumClasses][4];
     __shared__ long long s_base[kNumClasses];
     __shared__ long long s_red[8];
+    // the previous level did not run to completion (the loop ended there, or its recheck queue overflowed and it is
+    // going to be redone): nothing of this level may touch the working sets; the gate stays closed (counters are zeroed
+    // at run start)
+    if (prev != nullptr && !level_complete(prev, prev_qcap)) return;
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     RowInfo ri;
@@ -417,7 +425,7 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
         const unsigned long long nc = pair_mode ? (unsigned long long)d * (d - 1) / 2
                                                 : (L == 1 ? (unsigned long long)d : binom[(size_t)d * kBinomStride + L]);
         if (nc >= (1ull << 62))
-            cnt->overflow = 1;
+            atomicOr(&cnt->overflow, 1);
         else if (shard_world == 1 || row % shard_world == shard_rank)
         {  // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow check are global)
             int cls = 0;
@@ -487,14 +495,34 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
         ri.base = (int)s_base[ri.cls] + add + e;
         rowinfo[row] = ri;
     }
+    // ---- the level's gate: the last workgroup to arrive sees every total (agent-scope loads: the other workgroups'
+    // atomics were performed at the device's coherence point, not in this XCD's L2) ----
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        __threadfence();
+        const unsigned ticket = atomicAdd(&cnt->done_blocks, 1u);
+        if (ticket == gridDim.x - 1)
+        {
+            __threadfence();
+            const int maxdeg = __hip_atomic_load(&cnt->maxdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int ovf = __hip_atomic_load(&cnt->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            bool fits = true;
+            for (int c = 0; c < kNumClasses; c++)
+                fits = fits && (__hip_atomic_load(&cnt->class_items[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= item_cap);
+            cnt->item_overflow = fits ? 0 : 1;
+            cnt->active = (maxdeg - 1 >= L && ovf == 0 && fits) ? 1 : 0;
+        }
+    }
 }
 
 hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt, int shard_rank,
+                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt,
+                       const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap, int shard_rank,
                        int shard_world, hipStream_t st)
 {
     hipLaunchKernelGGL(plan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, deg, off, rowinfo, n, L, binom, chunk,
-                       staged_classes, pair_mode, cnt, shard_rank, shard_world);
+                       staged_classes, pair_mode, cnt, prev, prev_qcap, item_cap, shard_rank, shard_world);
     return hipGetLastError();
 }
 
@@ -503,28 +531,37 @@ struct ItemPtrs
     int2 *p[kNumClasses];
 };
 
-__global__ void fill_items_kernel(const RowInfo *__restrict__ rowinfo, int n, ItemPtrs ip)
+__global__ void fill_items_kernel(const RowInfo *__restrict__ rowinfo, int n, ItemPtrs ip, long long item_cap,
+                                  const LevelCounters *cnt)
 {
+    if (!cnt->active) return;  // also when the items would not fit: the host grows the buffers and resumes
     const int row = blockIdx.x;
     const RowInfo ri = rowinfo[row];
     if (ri.cls < 0) return;
     int2 *dst = ip.p[ri.cls];
     for (int c = threadIdx.x; c < ri.nchunks; c += blockDim.x) dst[ri.base + c] = make_int2(row, c);
+    (void)item_cap;
 }
 
-hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, hipStream_t st)
+hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, long long item_cap, const LevelCounters *cnt,
+                             hipStream_t st)
 {
     ItemPtrs ip;
     for (int c = 0; c < kNumClasses; c++) ip.p[c] = items[c];
-    hipLaunchKernelGGL(fill_items_kernel, dim3(n), dim3(64), 0, st, rowinfo, n, ip);
+    hipLaunchKernelGGL(fill_items_kernel, dim3(n), dim3(64), 0, st, rowinfo, n, ip, item_cap, cnt);
     return hipGetLastError();
 }
 
 // recoff = exclusive prefix of rowfound (256 rows per workgroup, prefix_256); level total; rec_base[level+1]
 __global__ void __launch_bounds__(256) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
-                                                        long long *rec_base, int level)
+                                                        unsigned long long qcap, long long *rec_base, int level)
 {
     __shared__ long long s_red[8];
+    if (!level_complete(cnt, qcap))
+    {  // the level did not run (or is going to be redone on the exact path): it contributes no records
+        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rec_base[level + 1] = rec_base[level];
+        return;
+    }
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int v = (row < n) ? rowfound[row] : 0;
     long long block_total;
@@ -538,10 +575,10 @@ __global__ void __launch_bounds__(256) rec_scan_kernel(const int *rowfound, int 
     }
 }
 
-hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, long long *rec_base, int level,
-                           hipStream_t st)
+hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, unsigned long long qcap,
+                           long long *rec_base, int level, hipStream_t st)
 {
-    hipLaunchKernelGGL(rec_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowfound, recoff, n, cnt, rec_base, level);
+    hipLaunchKernelGGL(rec_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowfound, recoff, n, cnt, qcap, rec_base, level);
     return hipGetLastError();
 }
 
@@ -560,18 +597,24 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_cnt[3];
-    const int2 item = p.items[blockIdx.x];
+    const int n = p.n;
+    const int tid = threadIdx.x;
+    if (tid < 3) s_cnt[tid] = 0ull;
+    unsigned long long ntests = 0, nrem = 0;
+    // persistent launch: the work items of the class are read on the device (the host does not know their number)
+    const long long nitems = level_items(p);
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
+    {
+    if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the LDS copy
+    const int2 item = p.items[it];
     const int X = item.x;
     const int o0 = p.off[X];
     const int d = p.off[X + 1] - o0;
-    const int n = p.n;
-    const int tid = threadIdx.x;
     unsigned long long *s_best = reinterpret_cast<unsigned long long *>(smem);
     int *s_nbr = reinterpret_cast<int *>(smem + sizeof(unsigned long long) * d);
     float *s_m1x = reinterpret_cast<float *>(s_nbr + d);
     int *s_ti = reinterpret_cast<int *>(s_m1x + d);
     const int *g_nbr = p.nbr + o0;
-    if (tid < 3) s_cnt[tid] = 0ull;
     for (int k = tid; k < d; k += kThreads)
     {
         const int y = g_nbr[k];
@@ -596,7 +639,6 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
     const unsigned long long q = (cntr + kThreads - 1) / kThreads;
     const unsigned long long lo = r0 + (unsigned long long)tid * q;
     const unsigned long long hi = min(r0 + cntr, lo + q);
-    unsigned long long ntests = 0, nrem = 0;
     if (lo < hi)
     {
         // unrank the pair: row a of the strict upper triangle starts at a*d - a(a+1)/2
@@ -671,11 +713,13 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
             }
         }
     }
+    }  // work items
     for (int o = 32; o > 0; o >>= 1)
     {
         ntests += __shfl_xor(ntests, o);
         nrem += __shfl_xor(nrem, o);
     }
+    __syncthreads();
     if ((tid & 63) == 0)
     {
         atomicAdd(&s_cnt[0], ntests);
@@ -690,13 +734,40 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
     }
 }
 
-hipError_t launch_pair(int mode, const SweepParams &p, long long nitems, size_t lds, hipStream_t st)
+// Workgroups of a persistent launch: as many as the chip holds at once for this kernel (twice that, so that a
+// workgroup that drew short items does not leave its slot empty), never more than the work-item buffer holds.
+unsigned persistent_grid(const void *kernel, int threads, size_t lds)
 {
-    if (nitems <= 0) return hipSuccess;
+    static std::mutex mu;
+    static std::map<std::pair<const void *, size_t>, unsigned> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_pair(kernel, lds);
+    auto it = cache.find(key);
+    if (it != cache.end()) return it->second;
+    int per_cu = 0, dev = 0, cus = 256;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, lds) != hipSuccess || per_cu <= 0)
+    {
+        (void)hipGetLastError();
+        per_cu = 1;
+    }
+    if (hipGetDevice(&dev) == hipSuccess)
+    {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) cus = v;
+    }
+    const unsigned g = (unsigned)std::max(1, per_cu) * (unsigned)cus * 2u;
+    cache[key] = g;
+    return g;
+}
+
+hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st)
+{
+    const void *kf = mode == 0 ? reinterpret_cast<const void *>(level1_pair_kernel<0>) : reinterpret_cast<const void *>(level1_pair_kernel<1>);
+    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(kf, kThreads, lds), std::max<long long>(p.item_cap, 1));
     if (mode == 0)
-        hipLaunchKernelGGL(level1_pair_kernel<0>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+        hipLaunchKernelGGL(level1_pair_kernel<0>, dim3(grid), dim3(kThreads), lds, st, p);
     else
-        hipLaunchKernelGGL(level1_pair_kernel<1>, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+        hipLaunchKernelGGL(level1_pair_kernel<1>, dim3(grid), dim3(kThreads), lds, st, p);
     return hipGetLastError();
 }
 
@@ -719,11 +790,11 @@ constexpr unsigned kNone32 = 0xffffffffu;
 
 __global__ void level1_prep_kernel(const float *__restrict__ C, const int *__restrict__ off, const int *__restrict__ nbr,
                                    const unsigned long long *__restrict__ adj, const int *__restrict__ wpre, int words,
-                                   float *rv, int4 *meta, unsigned *sel, int n)
+                                   float *rv, int4 *meta, unsigned *sel, int n, const LevelCounters *cnt)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= n) return;
+    if (row >= n || !cnt->active) return;
     const int o0 = off[row], d = off[row + 1] - o0;
     const int rw = row >> 6;
     const unsigned long long below = (1ull << (row & 63)) - 1ull;
@@ -806,6 +877,7 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     __shared__ unsigned long long s_cnt[4];
     const int ya = blockIdx.x;
     const int n = p.n;
+    if (!p.cnt->active) return;
     const int o0 = p.off[ya];
     const int d = p.off[ya + 1] - o0;
     if (d == 0 || ya + 1 >= n) return;
@@ -1040,9 +1112,10 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
 // directed edges
 __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict__ off, const unsigned *__restrict__ sel,
                                                            unsigned long long *best, int *rowfound, int n,
-                                                           unsigned long long *slots)
+                                                           unsigned long long *slots, const LevelCounters *cnt)
 {
     __shared__ int s_sum[4];
+    if (!cnt->active) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int c = 0;
@@ -1075,9 +1148,10 @@ __global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict
 // are counted
 __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict__ off, const int *__restrict__ nbr,
                                                            const unsigned *__restrict__ sel, unsigned long long *adj, int *deg,
-                                                           int n, int words, unsigned long long *slots)
+                                                           int n, int words, unsigned long long *slots, const LevelCounters *cnt)
 {
     __shared__ int s_sum[4];
+    if (!cnt->active) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int removed = 0;
@@ -1117,7 +1191,8 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
 
 hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st)
 {
-    hipLaunchKernelGGL(level1_count_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, p.n, p.slots);
+    hipLaunchKernelGGL(level1_count_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, p.n, p.slots,
+                       p.cnt);
     return hipGetLastError();
 }
 
@@ -1146,7 +1221,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
-                       static_cast<int4 *>(meta), sel, n);
+                       static_cast<int4 *>(meta), sel, n, p.cnt);
     RowsParams rp;
     rp.rv = rv;
     rp.meta = static_cast<const int4 *>(meta);
@@ -1170,11 +1245,11 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     {
         if (!defer_count)
             hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
-                               p.slots);
+                               p.slots, p.cnt);
     }
     else
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
-                           p.words, p.slots);
+                           p.words, p.slots, p.cnt);
     return hipGetLastError();
 }
 

@@ -14,6 +14,8 @@
 //   * selection state is kept chunk-relative in 32 bits (0 = decided below this chunk,
 //     0xffffffff = undecided), so four states are one ds_read_b128 as well.
 // Roughly 25 issued instructions per test at l = 5 instead of ~100.
+#include <algorithm>
+
 #include "ci_fast.h"
 #include "sweep_common.h"
 
@@ -54,28 +56,34 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_cnt[4];
 
-    const int2 item = p.items[blockIdx.x];
-    const int X = item.x;
-    const int o0 = p.off[X];
-    const int d = p.off[X + 1] - o0;
     const int n = p.n;
     const int tid = threadIdx.x;
-    const int ld4 = vec_ld4(d);
-    const int dp = (d + 3) & ~3;
-    const int *g_nbr = p.nbr + o0;
-
     const VecLayout lay = vec_layout(p.cap);
     unsigned *s_rel = reinterpret_cast<unsigned *>(smem + lay.rel);
     float *s_rowx = reinterpret_cast<float *>(smem + lay.rowx);
     int *s_nbr = reinterpret_cast<int *>(smem + lay.nbr);
     int *s_ti = reinterpret_cast<int *>(smem + lay.ti);
     float *s_sub = reinterpret_cast<float *>(smem + lay.sub);
+    if (tid < 4) s_cnt[tid] = 0ull;
+    unsigned long long ntests = 0, nsub = 0, nrem = 0;
+    // persistent launch: the class's work items are counted on the device (sweep_common.h: level_items); a workgroup
+    // takes the items blockIdx.x, blockIdx.x + gridDim.x, ... so that the chunks of one row spread over the chip
+    const long long nitems = level_items(p);
+    for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
+    {
+    if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the staged copy
+    const int2 item = p.items[it];
+    const int X = item.x;
+    const int o0 = p.off[X];
+    const int d = p.off[X + 1] - o0;
+    const int ld4 = vec_ld4(d);
+    const int dp = (d + 3) & ~3;
+    const int *g_nbr = p.nbr + o0;
 
     const unsigned long long ncomb = p.binom[(size_t)d * kBinomStride + L];
     const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
     const unsigned long long cntr = min(p.chunk, ncomb - r0);
 
-    if (tid < 4) s_cnt[tid] = 0ull;
     for (int k = tid; k <= d; k += kThreads)
     {
         const int v = (k < d) ? g_nbr[k] : X;
@@ -122,7 +130,6 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     const float t2lo = p.t2 * (1.0f - kBeta), t2hi = p.t2 * (1.0f + kBeta);
     [[maybe_unused]] const int tiX = (MODE == 1) ? s_ti[d] : 0;
 
-    unsigned long long ntests = 0, nsub = 0, nrem = 0;
     if (lo < hi)
     {
         int idx[L];
@@ -267,12 +274,14 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
             }
         }
     }
+    }  // work items
     for (int o = 32; o > 0; o >>= 1)
     {
         ntests += __shfl_xor(ntests, o);
         nsub += __shfl_xor(nsub, o);
         nrem += __shfl_xor(nrem, o);
     }
+    __syncthreads();
     if ((tid & 63) == 0)
     {
         if (ntests) atomicAdd(&s_cnt[0], ntests);
@@ -291,9 +300,8 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 size_t sweep_vec_lds_bytes(int cls) { return vec_layout(kClassCap[cls]).total; }
 
 template <int L, int MODE>
-static hipError_t launch_vec_L(const SweepParams &p, int cls, long long nitems, hipStream_t st)
+static hipError_t launch_vec_L(const SweepParams &p, int cls, hipStream_t st)
 {
-    if (nitems <= 0) return hipSuccess;
     const size_t lds = vec_layout(kClassCap[cls]).total;
     auto kfn = sweep_vec_kernel<L, MODE>;
     if (lds > 64 * 1024)
@@ -302,16 +310,18 @@ static hipError_t launch_vec_L(const SweepParams &p, int cls, long long nitems, 
             hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nitems), dim3(kThreads), lds, st, p);
+    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
+                                                        std::max<long long>(p.item_cap, 1));
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, long long nitems, hipStream_t st)
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, hipStream_t st)
 {
     switch (L)
     {
 #define CUSK_CASE(LL) \
-    case LL: return mode == 0 ? launch_vec_L<LL, 0>(p, cls, nitems, st) : launch_vec_L<LL, 1>(p, cls, nitems, st);
+    case LL: return mode == 0 ? launch_vec_L<LL, 0>(p, cls, st) : launch_vec_L<LL, 1>(p, cls, st);
         CUSK_CASE(2)
         CUSK_CASE(3)
         CUSK_CASE(4)

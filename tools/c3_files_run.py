@@ -20,7 +20,7 @@ del Ct
 torch.cuda.empty_cache()
 with open(os.path.join(d, "mxm.bin"), "wb") as f:  # lower triangle incl. diagonal, row-major
     for i0 in range(0, m, 2048):
-        rows = Ch[i0:i0 + 2048, :m]
+        rows = Ch[i0:min(i0 + 2048, m), :m]
         f.write(np.concatenate([rows[k, : i0 + k + 1] for k in range(rows.shape[0])]).astype(np.float32).tobytes())
 names = [f"T{k}" for k in range(p)]
 with open(os.path.join(d, "mxp.txt"), "w") as f:
