@@ -51,6 +51,7 @@ struct DevBuf
 };
 
 struct LevelCounters;  // sweep_common.h
+struct HostGate;       // sweep_common.h
 
 }  // namespace cusk
 
@@ -71,10 +72,19 @@ struct cusk_engine
     cusk::DevBuf adj, adj0;  // uint64 n*words: live adjacency, adjacency after level 0
     cusk::DevBuf deg, binom, counters, slots, rec_base, ti, queue, symflag;
     // per-level working sets, ping-pong by level parity
-    cusk::DevBuf off[2], nbr[2], best[2], rowinfo[2], rowfound[2], recoff[2];
+    cusk::DevBuf off[2], nbr[2], best[2];
+    cusk::DevBuf off1;  // CSR offsets of level 1 (kept for the whole run: records live at level-1 slots)
     cusk::DevBuf items[2][cusk::kNumClasses];
-    cusk::DevBuf rec_x, rec_y, rec_l, rec_z, rec_s;
-    long long rec_cap = 0;  // records allocated (= directed edges after level 0); rec_s is member-major with this stride
+    // sparse record store, indexed by level-1 CSR slot (rec_l = 0: empty); rec_s is member-major with stride rec_cap
+    cusk::DevBuf rec_x, rec_y, rec_l, rec_s;
+    long long rec_cap = 0;    // slots allocated
+    long long rec_slots = 0;  // slots of the last run (= directed edges after level 0)
+    // dense record list, produced on the first result request after a run (materialize_records)
+    cusk::DevBuf den_x, den_y, den_l, den_z, den_s, den_counts, den_off;
+    long long den_stride = 0;
+    bool records_ready = false, z_ready = false;
+    const float *last_C = nullptr;  // matrix of the last run (the winners' z is computed from it on request)
+    int last_levels = 0;
     cusk::DevBuf rv, rpos, sel, wpre;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors
@@ -84,8 +94,10 @@ struct cusk_engine
     int *hflag = nullptr;
     std::vector<unsigned long long> binom_host;
     long long binom_rows = 0;  // rows of the device-resident binomial table
-    hipEvent_t ev_cnt = nullptr;  // the level counters have reached the pinned mirror
-    hipEvent_t ev_cntl[cusk::kLevels];  // ... per level: the host follows the device at a distance (engine.hip)
+    // per level: what the level's plan kernel tells the host, written straight into pinned host memory (the host follows
+    // the device at a distance, engine.hip); run_seq tags the entries of the current run
+    cusk::HostGate *hgate = nullptr, *hgate_dev = nullptr;
+    int run_seq = 0;
     long long item_cap_cur = 0;         // capacity (entries) of the per-class work-item buffers
     hipEvent_t ev_main[2] = {nullptr, nullptr};  // around the level-1 rows kernel alone
     hipEvent_t ev_run[2] = {nullptr, nullptr};
@@ -104,7 +116,8 @@ struct cusk_engine
     long long opt_queue_cap = 4ll << 20;
     long long opt_chunk = 2048;
     long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
-    int opt_lookahead = 2;               // levels the host may enqueue ahead of the counters it has seen
+    int opt_lookahead = 2;
+    int opt_timing = 1;                  // per-level HIP events for cusk_stats' kernel_ms / level_ms (0: total only)               // levels the host may enqueue ahead of the counters it has seen
     long long opt_sep_ws_budget = 4ll << 30;  // HBM work space of cusk_sepselect_greedy for candidate lists beyond LDS
 
     // row-sharded sweep of ONE block over several engines: this engine runs the tests of rows

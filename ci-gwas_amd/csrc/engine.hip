@@ -13,6 +13,7 @@
 // back once at the end.  Two CSR working sets alternate by level parity so that a level
 // whose recheck queue overflowed can be redone on the exact path after the fact.
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
 
@@ -118,17 +119,22 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     const size_t ctl_cnt = kCtlCnt, ctl_slots = kCtlSlots, ctl_recbase = kCtlRecBase, ctl_sym = kCtlSym;
     const size_t ctl_bytes = kCtlBytes;
     CUSK_HIP(e, e->counters.ensure(ctl_bytes));
+    long long &item_cap = e->item_cap_cur;
+    item_cap = std::max<long long>(item_cap, std::max<long long>(e->opt_item_cap, 1024));
     for (int k = 0; k < 2; k++)
     {
         CUSK_HIP(e, e->off[k].ensure(sizeof(int) * ((size_t)n + 1)));
-        CUSK_HIP(e, e->rowinfo[k].ensure(sizeof(RowInfo) * (size_t)n));
-        CUSK_HIP(e, e->rowfound[k].ensure(sizeof(int) * (size_t)n));
-        CUSK_HIP(e, e->recoff[k].ensure(sizeof(int) * (size_t)n));
+        for (int c = 0; c < kNumClasses; c++) CUSK_HIP(e, e->items[k][c].ensure(sizeof(int2) * (size_t)item_cap));
     }
+    CUSK_HIP(e, e->off1.ensure(sizeof(int) * ((size_t)n + 1)));
+    const int run_seq = ++e->run_seq;
+    e->records_ready = e->z_ready = false;
+    e->rec_slots = 0;
+    e->last_C = a.C;
     char *ctl = e->counters.as<char>();
     LevelCounters *dcnt = reinterpret_cast<LevelCounters *>(ctl + ctl_cnt);
     unsigned long long *dslots = reinterpret_cast<unsigned long long *>(ctl + ctl_slots);
-    long long *drec_base = reinterpret_cast<long long *>(ctl + ctl_recbase);
+    (void)ctl_recbase;
     int *dsym = reinterpret_cast<int *>(ctl + ctl_sym);
     CUSK_HIP(e, hipMemsetAsync(ctl, 0, ctl_bytes, s));
     if (a.mode == 1)
@@ -166,8 +172,6 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // level that is run (or redone) on the exact path has no queue: ~0.
     unsigned long long qcap_gate[kLevels];
     for (auto &q : qcap_gate) q = ~0ull;
-    long long &item_cap = e->item_cap_cur;
-    item_cap = std::max<long long>(item_cap, std::max<long long>(e->opt_item_cap, 1024));
 
     auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
         LevelPlan &pl = plan[l];
@@ -179,8 +183,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (pl.use_rows && !exact_only)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
-                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->ev_main[0], e->ev_main[1],
-                                           e->shard_rank, e->shard_world, sharded, s));
+                                           e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->opt_timing ? e->ev_main[0] : nullptr,
+                                           e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, s));
             rows_timed = true;
             return CUSK_OK;
         }
@@ -236,11 +240,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (a.mode != 0) return CUSK_OK;
         LevelPlan &pl = plan[l];
         pl.fp.qcap = qcap_gate[l];
-        CUSK_HIP(e, launch_rec_scan(e->rowfound[l & 1].as<int>(), e->recoff[l & 1].as<int>(), n, dcnt + l, qcap_gate[l], drec_base,
-                                    l, s));
-        // the winners' exact z (record_z) is off the critical path: it runs on the auxiliary stream while
-        // the next level's compaction proceeds
-        CUSK_HIP(e, launch_finalize(l, pl.fp, s, e->opt_overlap ? e->stream2 : s, e->ev_z));
+        // separating-set records in place (level-1 slot of the pair), bitmap rows and degrees; the winners' exact z is
+        // computed when somebody asks for it
+        CUSK_HIP(e, launch_finalize(l, pl.fp, s));
         return CUSK_OK;
     };
 
@@ -261,7 +263,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 if (rc != CUSK_OK) return rc;
             }
         }
-        const size_t count = (size_t)e->hcnt[l].total_edges;
+        const size_t count = (size_t)e->hgate[l].total_edges;
         const int elem = pl.use_rows ? 4 : 8;
         void *dev = pl.use_rows ? e->sel.p : e->best[l & 1].p;
         int rc = 0;
@@ -287,10 +289,6 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             rc = e->shard_fn(e->shard_user, l, dev, count, elem, 1, (void *)s);
         }
         if (rc != 0) return fail(e, CUSK_ERR_ARG, "row-shard exchange failed at level " + std::to_string(l));
-        if (pl.use_rows)
-            CUSK_HIP(e, launch_level1_count(pl.sp, e->sel.as<unsigned>(), s));
-        else
-            CUSK_HIP(e, launch_count_found(pl.sp.off, pl.sp.best, pl.sp.rowfound, n, s));
         return CUSK_OK;
     };
 
@@ -307,6 +305,26 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // ended; that wait overlaps the device's work on the levels in between.  Row-sharded runs call back into the host
     // every level and follow at distance 0.
     const int lookahead = sharded ? 0 : std::max(0, e->opt_lookahead);
+    // the level's plan kernel writes its gate record into pinned host memory; spin until this run's record is there
+    auto wait_gate = [&](int l) -> int {
+        volatile int *seq = &e->hgate[l].seq;
+        for (unsigned long it = 1; *seq != run_seq; it++)
+        {
+            if ((it & 0x3fff) == 0)
+            {
+                const hipError_t q = hipStreamQuery(s);
+                if (q == hipSuccess)
+                {
+                    if (*seq == run_seq) break;
+                    return fail(e, CUSK_ERR_HIP, "level " + std::to_string(l) + ": the stream drained without the level's gate record");
+                }
+                if (q != hipErrorNotReady) return fail(e, CUSK_ERR_HIP, std::string("stream error while waiting for a level gate: ") + hipGetErrorString(q));
+            }
+            __builtin_ia32_pause();
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        return CUSK_OK;
+    };
     int maxdeg1 = 0;
     int start = 1;   // first level to enqueue in this pass
     int redo = 0;    // level whose recheck queue overflowed: its sweeps run again on the exact path before `start`
@@ -323,7 +341,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (rc != CUSK_OK) return rc;
             rc = launch_level_finalize(redo);
             if (rc != CUSK_OK) return rc;
-            CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
+            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
             redo = 0;
         }
         int enq_last = start - 1;
@@ -334,40 +352,58 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 const int k = l - 1 - lookahead;
                 if (k >= start)
                 {
-                    CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[k]));
-                    if (!e->hcnt[k].active) break;
+                    const int rc = wait_gate(k);
+                    if (rc != CUSK_OK) return rc;
+                    if (!e->hgate[k].active) break;
                 }
             }
-            CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
+            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
             LevelPlan &pl = plan[l];
             pl.redone = false;
             pl.known_items = false;
             const bool first_build = (l == 1 && first_pass);
-            const LevelCounters *prev = (l >= 2) ? dcnt + (l - 1) : nullptr;
-            const unsigned long long prev_q = (l >= 2) ? qcap_gate[l - 1] : ~0ull;
-            // 1. the plan of the level from the degrees alone (level 1 is planned for the generic kernels first: whether
-            //    the matrix is symmetric is only known with the first read-back, and the row-streaming kernel does not
-            //    use work items)
-            bool pair_items = (l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows;
-            CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
-                                    e->binom.as<unsigned long long>(), chunk, staged_classes, pair_items ? 1 : 0, dcnt + l, prev,
-                                    prev_q, item_cap, e->shard_rank, e->shard_world, s));
-            if (first_build) CUSK_HIP(e, hipMemcpyAsync(e->hflag, dsym, sizeof(int), hipMemcpyDeviceToHost, s));
-            CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
-            CUSK_HIP(e, hipEventRecord(e->ev_cntl[l], s));
+            int *off_l = (l == 1) ? e->off1.as<int>() : e->off[cs].as<int>();
+            // 1. the plan of the level from the degrees alone: offsets, work items, totals, gate (level 1 is planned for
+            //    the generic kernels first: whether the matrix is symmetric is only known with the first read-back, and the
+            //    row-streaming kernel does not use work items)
+            PlanArgs pa;
+            pa.deg = e->deg.as<int>();
+            pa.off = off_l;
+            for (int c = 0; c < kNumClasses; c++) pa.items[c] = e->items[cs][c].as<int2>();
+            pa.n = n;
+            pa.L = l;
+            pa.binom = e->binom.as<unsigned long long>();
+            pa.chunk = chunk;
+            pa.staged_classes = staged_classes;
+            pa.pair_mode = ((l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows) ? 1 : 0;
+            pa.cnt = dcnt + l;
+            pa.prev = (l >= 2) ? dcnt + (l - 1) : nullptr;
+            pa.prev_qcap = (l >= 2) ? qcap_gate[l - 1] : ~0ull;
+            pa.item_cap = item_cap;
+            pa.shard_rank = e->shard_rank;
+            pa.shard_world = e->shard_world;
+            pa.gate = e->hgate_dev + l;
+            pa.seq = run_seq;
+            pa.sym = (l == 1 && !e->opt_assume_symmetric) ? dsym : nullptr;
+            if (first_build && e->binom_rows <= 0)
+            {  // the plan reads C(d, 1) = d only at level 1, but wants a valid table pointer
+                CUSK_HIP(e, e->binom.ensure(sizeof(unsigned long long) * kBinomStride));
+                pa.binom = e->binom.as<unsigned long long>();
+            }
+            CUSK_HIP(e, launch_plan(pa, s));
             if (first_build)
             {
                 // the run's one mandatory round trip: sizes of the CSR arrays and of the binomial table come from the
                 // level-1 degrees
-                CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[l]));
-                symmetric = (*e->hflag == 0) || (e->opt_assume_symmetric != 0);
-                cap_edges = std::max<long long>(e->hcnt[1].total_edges, 1);
-                maxdeg1 = e->hcnt[1].maxdeg;
+                int rc = wait_gate(1);
+                if (rc != CUSK_OK) return rc;
+                symmetric = (e->hgate[1].sym == 0) || (e->opt_assume_symmetric != 0);
+                cap_edges = std::max<long long>(e->hgate[1].total_edges, 1);
+                maxdeg1 = e->hgate[1].maxdeg;
                 for (int k = 0; k < 2; k++)
                 {
                     CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
                     if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
-                    for (int c = 0; c < kNumClasses; c++) CUSK_HIP(e, e->items[k][c].ensure(sizeof(int2) * (size_t)item_cap));
                 }
                 CUSK_HIP(e, e->rv.ensure(sizeof(float) * (size_t)cap_edges));
                 CUSK_HIP(e, e->rpos.ensure(sizeof(int) * 4 * (size_t)cap_edges));
@@ -377,10 +413,13 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     CUSK_HIP(e, e->rec_x.ensure(sizeof(int) * (size_t)cap_edges));
                     CUSK_HIP(e, e->rec_y.ensure(sizeof(int) * (size_t)cap_edges));
                     CUSK_HIP(e, e->rec_l.ensure(sizeof(int) * (size_t)cap_edges));
-                    CUSK_HIP(e, e->rec_z.ensure(sizeof(float) * (size_t)cap_edges));
                     CUSK_HIP(e, e->rec_s.ensure(sizeof(int) * kML * (size_t)cap_edges));
+                    e->rec_cap = (long long)(e->rec_l.cap / sizeof(int));
+                    if ((long long)(e->rec_s.cap / (sizeof(int) * kML)) < e->rec_cap) e->rec_cap = (long long)(e->rec_s.cap / (sizeof(int) * kML));
+                    e->rec_slots = cap_edges;
+                    CUSK_HIP(e, hipMemsetAsync(e->rec_l.p, 0, sizeof(int) * (size_t)cap_edges, s));  // no records yet
+                    CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
                 }
-                e->rec_cap = cap_edges;
                 CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
                 // binomial table C(a, b), a <= max degree: kept on the device across runs
                 if ((long long)maxdeg1 >= e->binom_rows)
@@ -403,49 +442,42 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 if (pl.use_pair && !pl.use_rows)
                 {  // the pair kernel counts its work items differently: plan again (option rows = 0 only)
                     CUSK_HIP(e, hipMemsetAsync(dcnt + l, 0, sizeof(LevelCounters), s));
-                    CUSK_HIP(e, launch_plan(e->deg.as<int>(), e->off[cs].as<int>(), e->rowinfo[cs].as<RowInfo>(), n, l,
-                                            e->binom.as<unsigned long long>(), chunk, staged_classes, 1, dcnt + l, prev, prev_q,
-                                            item_cap, e->shard_rank, e->shard_world, s));
-                    CUSK_HIP(e, hipMemcpyAsync(e->hcnt, dcnt, sizeof(LevelCounters) * kLevels, hipMemcpyDeviceToHost, s));
-                    CUSK_HIP(e, hipEventRecord(e->ev_cntl[l], s));
+                    pa.pair_mode = 1;
+                    pa.binom = e->binom.as<unsigned long long>();
+                    pa.seq = run_seq;
+                    e->hgate[1].seq = 0;
+                    CUSK_HIP(e, launch_plan(pa, s));
                 }
                 first_pass = false;
             }
             if (sharded)
             {  // the exchange below is a collective: every engine must know now whether the level runs
-                CUSK_HIP(e, hipEventSynchronize(e->ev_cntl[l]));
-                if (!e->hcnt[l].active) break;
-                for (int c = 0; c < kNumClasses; c++) pl.nitems[c] = e->hcnt[l].class_items[c];
+                const int rc = wait_gate(l);
+                if (rc != CUSK_OK) return rc;
+                if (!e->hgate[l].active) break;
+                for (int c = 0; c < kNumClasses; c++) pl.nitems[c] = e->hgate[l].class_items[c];
                 pl.known_items = true;
             }
             {  // degrees only shrink: the newest level whose counters have arrived bounds every later one
                 pl.maxdeg_bound = maxdeg1;
                 const int k = l - 1 - lookahead;
-                if (k >= 1 && e->hcnt[k].active) pl.maxdeg_bound = std::min(maxdeg1, e->hcnt[k].maxdeg);
+                if (k >= 1 && e->hgate[k].seq == run_seq && e->hgate[k].active) pl.maxdeg_bound = std::min(maxdeg1, e->hgate[k].maxdeg);
                 pl.staged_classes = staged_classes;
             }
             pl.use_fast = (e->opt_fast != 0) && (l >= 2);
-            // 2. neighbour lists and work items (no host dependency)
-            CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), e->off[cs].as<int>(), e->nbr[cs].as<int>(),
-                                        (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr,
-                                        a.mode == 0 ? e->rowfound[cs].as<int>() : nullptr, n, words,
-                                        pl.use_rows ? e->wpre.as<int>() : nullptr, dcnt + l, s));
-            if (!pl.use_rows)
-            {
-                int2 *iptr[kNumClasses];
-                for (int c = 0; c < kNumClasses; c++) iptr[c] = e->items[cs][c].as<int2>();
-                CUSK_HIP(e, launch_fill_items(e->rowinfo[cs].as<RowInfo>(), n, iptr, item_cap, dcnt + l, s));
-            }
+            // 2. the neighbour lists (no host dependency)
+            CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), off_l, e->nbr[cs].as<int>(),
+                                        (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr, n, words,
+                                        (l == 1 && (pl.use_rows || a.mode == 0)) ? e->wpre.as<int>() : nullptr, dcnt + l, s));
 
             SweepParams &sp = pl.sp;
             sp.C = a.C;
             sp.Ness = a.Ness;
             sp.n = n;
             sp.level = l;
-            sp.off = e->off[cs].as<int>();
+            sp.off = off_l;
             sp.nbr = e->nbr[cs].as<int>();
             sp.best = e->best[cs].as<unsigned long long>();
-            sp.rowfound = e->rowfound[cs].as<int>();
             sp.adj = e->adj.as<unsigned long long>();
             sp.deg = e->deg.as<int>();
             sp.words = words;
@@ -488,27 +520,29 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             fp.off = sp.off;
             fp.nbr = sp.nbr;
             fp.best = sp.best;
-            fp.recoff = e->recoff[cs].as<int>();
-            fp.rec_base = drec_base;
+            fp.sel = pl.use_rows ? e->sel.as<unsigned>() : nullptr;
             fp.level = l;
             fp.adj = sp.adj;
             fp.deg = sp.deg;
             fp.words = words;
             fp.binom = sp.binom;
+            fp.off1 = e->off1.as<int>();
+            fp.wpre1 = e->wpre.as<int>();
+            fp.adj0 = e->adj0.as<unsigned long long>();
             fp.rec_x = e->rec_x.as<int>();
             fp.rec_y = e->rec_y.as<int>();
             fp.rec_l = e->rec_l.as<int>();
             fp.rec_s = e->rec_s.as<int>();
             fp.rec_cap = e->rec_cap;
-            fp.rec_z = e->rec_z.as<float>();
             fp.meta = pl.use_rows ? e->rpos.as<int4>() : nullptr;
             fp.cnt = dcnt + l;
             fp.qcap = qcap_gate[l];
+            fp.slots = sp.slots;
 
-            CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
+            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
             int rc = launch_level_sweeps(l, false);
             if (rc != CUSK_OK) return rc;
-            CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
+            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
             if (sharded)
             {
                 rc = shard_join(l);
@@ -516,7 +550,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             }
             rc = launch_level_finalize(l);
             if (rc != CUSK_OK) return rc;
-            CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
+            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
             enq_last = l;
         }
 
@@ -557,7 +591,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (ended) level_out = ended - 1;  // cuPC-S.cu:154-159
             break;
         }
-        // resume: the counters of the levels that are enqueued again start from zero
+        // resume: the counters of the levels that are enqueued again start from zero, their gate records are void
+        for (int l = start; l < kLevels; l++) e->hgate[l].seq = 0;
         if (start <= last_level)
         {
             CUSK_HIP(e, hipMemsetAsync(dcnt + start, 0, sizeof(LevelCounters) * (size_t)(kLevels - start), s));
@@ -575,6 +610,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     float ms = 0.0f;
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[0], e->ev_l1[0]));
     local.kernel_ms[0] = local.level_ms[0] = ms;
+    const bool timed = e->opt_timing != 0;
     for (int l = 1; l <= levels_swept; l++)
     {
         for (int k = 0; k < kCounterSlots; k++)
@@ -586,6 +622,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             local.violations += (long long)sl[3];
         }
         local.rechecks[l] = (long long)e->hcnt[l].qcount;
+        if (!timed) continue;
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_k0[l], e->ev_k1[l]));
         local.kernel_ms[l] = ms;
         local.main_kernel_ms[l] = ms;
@@ -600,7 +637,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_run[0], e->ev_run[1]));
     local.total_ms = ms;
     local.level = level_out;
-    if (a.mode == 0) e->nrec = e->hrec_base[levels_swept + 1];
+    e->last_levels = levels_swept;
+    e->nrec = 0;  // the dense record list is produced on request (materialize_records)
     e->have_result = true;
     if (st) *st = local;
     return CUSK_OK;
@@ -628,7 +666,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
     if (hipSetDevice(device) != hipSuccess) return CUSK_ERR_HIP;
     cusk_engine *e = new cusk_engine();
     e->device = device;
-    for (int l = 0; l < kLevels; l++) e->ev_k0[l] = e->ev_k1[l] = e->ev_l0[l] = e->ev_l1[l] = e->ev_cntl[l] = nullptr;
+    for (int l = 0; l < kLevels; l++) e->ev_k0[l] = e->ev_k1[l] = e->ev_l0[l] = e->ev_l1[l] = nullptr;
     bool ok = true;
     if (stream)
     {
@@ -655,15 +693,20 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         }
     }
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;
+    // gate records: the plan kernels store into this pinned, coherent host memory directly
+    ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hgate), sizeof(HostGate) * kLevels, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess;
+    if (ok)
+    {
+        std::memset(e->hgate, 0, sizeof(HostGate) * kLevels);
+        ok = hipHostGetDevicePointer(reinterpret_cast<void **>(&e->hgate_dev), e->hgate, 0) == hipSuccess;
+    }
     for (auto &ev : e->ev_run) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (auto &ev : e->ev_main) ok = ok && hipEventCreate(&ev) == hipSuccess;
-    ok = ok && hipEventCreateWithFlags(&e->ev_cnt, hipEventDisableTiming) == hipSuccess;
     for (auto &ev : e->ev_corr) ok = ok && hipEventCreate(&ev) == hipSuccess;
     for (int l = 0; l < kLevels; l++)
     {
         ok = ok && hipEventCreate(&e->ev_k0[l]) == hipSuccess && hipEventCreate(&e->ev_k1[l]) == hipSuccess;
         ok = ok && hipEventCreate(&e->ev_l0[l]) == hipSuccess && hipEventCreate(&e->ev_l1[l]) == hipSuccess;
-        ok = ok && hipEventCreateWithFlags(&e->ev_cntl[l], hipEventDisableTiming) == hipSuccess;
     }
     if (!ok)
     {
@@ -680,26 +723,27 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
-                      &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_z, &e->rec_s, &e->bed_dev, &e->phen_dev,
+                      &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_s, &e->den_x, &e->den_y, &e->den_l,
+                      &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)
     {
-        for (DevBuf *b : {&e->off[k], &e->nbr[k], &e->best[k], &e->rowinfo[k], &e->rowfound[k], &e->recoff[k]}) b->release();
+        for (DevBuf *b : {&e->off[k], &e->nbr[k], &e->best[k]}) b->release();
         for (auto &b : e->items[k]) b.release();
     }
     if (e->shard_host) (void)hipHostFree(e->shard_host);
     if (e->hcnt) (void)hipHostFree(e->hcnt);
     if (e->hflag) (void)hipHostFree(e->hflag);
+    if (e->hgate) (void)hipHostFree(e->hgate);
     for (auto &ev : e->ev_run)
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : e->ev_main)
         if (ev) (void)hipEventDestroy(ev);
-    if (e->ev_cnt) (void)hipEventDestroy(e->ev_cnt);
     for (auto &ev : e->ev_corr)
         if (ev) (void)hipEventDestroy(ev);
     for (int l = 0; l < kLevels; l++)
-        for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l], e->ev_cntl[l]})
+        for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
             if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
@@ -742,6 +786,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
     }
     else if (k == "lookahead" && value >= 0)
         e->opt_lookahead = (int)value;
+    else if (k == "timing")
+        e->opt_timing = (int)value;
     else if (k == "sepselect_ws_bytes" && value > 0)
         e->opt_sep_ws_budget = value;
     else
@@ -837,15 +883,77 @@ extern "C" int cusk_result_adj_i32(cusk_engine *e, int *G_host)
     return rc;
 }
 
+// Result read-out, off the hot path: the sparse record store (level-1 slots) becomes a dense list ordered by slot,
+// i.e. by (x, y); then, when asked for, the winners' exact Fisher z level by level.
+static int materialize_records(cusk_engine *e, bool want_z)
+{
+    hipStream_t s = e->stream;
+    if (!e->records_ready)
+    {
+        e->nrec = 0;
+        const long long slots = e->rec_slots;
+        if (slots > 0)
+        {
+            const long long nb = (slots + kRecBlock - 1) / kRecBlock;
+            CUSK_HIP(e, e->den_counts.ensure(sizeof(int) * (size_t)nb));
+            CUSK_HIP(e, e->den_off.ensure(sizeof(long long) * (size_t)nb));
+            CUSK_HIP(e, launch_rec_count(e->rec_l.as<int>(), slots, e->den_counts.as<int>(), s));
+            std::vector<int> counts((size_t)nb);
+            CUSK_HIP(e, hipMemcpyAsync(counts.data(), e->den_counts.p, sizeof(int) * (size_t)nb, hipMemcpyDeviceToHost, s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+            std::vector<long long> off((size_t)nb);
+            long long tot = 0;
+            for (long long b = 0; b < nb; b++)
+            {
+                off[(size_t)b] = tot;
+                tot += counts[(size_t)b];
+            }
+            e->nrec = tot;
+            if (tot > 0)
+            {
+                CUSK_HIP(e, e->den_x.ensure(sizeof(int) * (size_t)tot));
+                CUSK_HIP(e, e->den_y.ensure(sizeof(int) * (size_t)tot));
+                CUSK_HIP(e, e->den_l.ensure(sizeof(int) * (size_t)tot));
+                CUSK_HIP(e, e->den_z.ensure(sizeof(float) * (size_t)tot));
+                CUSK_HIP(e, e->den_s.ensure(sizeof(int) * kML * (size_t)tot));
+                e->den_stride = tot;
+                CUSK_HIP(e, hipMemcpyAsync(e->den_off.p, off.data(), sizeof(long long) * (size_t)nb, hipMemcpyHostToDevice, s));
+                CUSK_HIP(e, launch_rec_compact(e->rec_l.as<int>(), e->rec_x.as<int>(), e->rec_y.as<int>(), e->rec_s.as<int>(),
+                                               e->rec_cap, slots, e->den_off.as<long long>(), e->den_x.as<int>(), e->den_y.as<int>(),
+                                               e->den_l.as<int>(), e->den_s.as<int>(), e->den_stride, s));
+                CUSK_HIP(e, hipStreamSynchronize(s));  // `off` lives on this stack frame
+            }
+        }
+        e->records_ready = true;
+        e->z_ready = false;
+    }
+    if (want_z && !e->z_ready)
+    {
+        if (e->nrec > 0)
+        {
+            if (!e->last_C) return fail(e, CUSK_ERR_STATE, "the matrix of the last run is needed for the separating sets' z");
+            for (int l = 1; l <= e->last_levels; l++)
+                CUSK_HIP(e, launch_record_z(l, e->last_C, e->n, e->den_x.as<int>(), e->den_y.as<int>(), e->den_l.as<int>(),
+                                            e->den_s.as<int>(), e->den_stride, e->nrec, e->den_z.as<float>(), s));
+            CUSK_HIP(e, hipStreamSynchronize(s));
+        }
+        e->z_ready = true;
+    }
+    return CUSK_OK;
+}
+
 extern "C" int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_host)
 {
     if (!e || !e->have_result || e->mode != 0) return fail(e, CUSK_ERR_STATE, "no Skeleton result");
     CUSK_HIP(e, hipSetDevice(e->device));
+    if (C_dev) e->last_C = C_dev;
+    int rc = materialize_records(e, true);
+    if (rc != CUSK_OK) return rc;
     const size_t bytes = sizeof(float) * (size_t)e->n * e->n;
     float *tmp = nullptr;
     CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
     hipError_t st = launch_expand_pmax(e->adj.as<unsigned long long>(), e->adj0.as<unsigned long long>(), C_dev, tmp, e->n,
-                                       e->words, e->rec_x.as<int>(), e->rec_y.as<int>(), e->rec_z.as<float>(), e->nrec,
+                                       e->words, e->den_x.as<int>(), e->den_y.as<int>(), e->den_z.as<float>(), e->nrec,
                                        e->stream);
     if (st == hipSuccess) st = hipMemcpyAsync(pMax_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
     if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
@@ -860,7 +968,7 @@ static int records_to_host(cusk_engine *e, int *S_host)
     int *tmp = nullptr;
     const size_t bytes = sizeof(int) * kML * (size_t)e->nrec;
     CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
-    hipError_t st = launch_expand_records(e->rec_s.as<int>(), e->rec_l.as<int>(), e->rec_cap, e->nrec, tmp, e->stream);
+    hipError_t st = launch_expand_records(e->den_s.as<int>(), e->den_l.as<int>(), e->den_stride, e->nrec, tmp, e->stream);
     if (st == hipSuccess) st = hipMemcpyAsync(S_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
     if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
     (void)hipFree(tmp);
@@ -872,15 +980,17 @@ extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
 {
     if (!e || !e->have_result || e->mode != 0) return fail(e, CUSK_ERR_STATE, "no Skeleton result");
     CUSK_HIP(e, hipSetDevice(e->device));
+    int rc = materialize_records(e, false);
+    if (rc != CUSK_OK) return rc;
     const size_t count = (size_t)e->n * e->n * kML;
     // the dense n*n*14 array exists only for the reference's ABI; it is filled on the host
     std::fill(SepSet_host, SepSet_host + count, -1);
     if (e->nrec > 0)
     {
         std::vector<int> x(e->nrec), y(e->nrec), S((size_t)e->nrec * kML);
-        CUSK_HIP(e, hipMemcpy(x.data(), e->rec_x.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
-        CUSK_HIP(e, hipMemcpy(y.data(), e->rec_y.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
-        int rc = records_to_host(e, S.data());
+        CUSK_HIP(e, hipMemcpy(x.data(), e->den_x.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
+        CUSK_HIP(e, hipMemcpy(y.data(), e->den_y.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
+        rc = records_to_host(e, S.data());
         if (rc != CUSK_OK) return rc;
         for (long long r = 0; r < e->nrec; r++)
             std::memcpy(SepSet_host + ((size_t)x[r] * e->n + y[r]) * kML, S.data() + (size_t)r * kML, sizeof(int) * kML);
@@ -892,13 +1002,14 @@ extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *le
 {
     if (!e || !e->have_result || e->mode != 0) return -1;
     if (hipSetDevice(e->device) != hipSuccess) return -1;
+    if (materialize_records(e, z != nullptr) != CUSK_OK) return -1;
     const long long c = e->nrec;
     if (c > 0)
     {
-        if (x && hipMemcpy(x, e->rec_x.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (y && hipMemcpy(y, e->rec_y.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (level && hipMemcpy(level, e->rec_l.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (z && hipMemcpy(z, e->rec_z.p, sizeof(float) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (x && hipMemcpy(x, e->den_x.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (y && hipMemcpy(y, e->den_y.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (level && hipMemcpy(level, e->den_l.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (z && hipMemcpy(z, e->den_z.p, sizeof(float) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
         if (S && records_to_host(e, S) != CUSK_OK) return -1;
     }
     return c;

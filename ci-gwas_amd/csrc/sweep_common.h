@@ -42,6 +42,16 @@ struct LevelCounters
     int pad;
 };
 
+// What the host needs to know about a level to follow the device, written by the level's plan kernel straight into
+// pinned host memory (no copy, no event on the stream); seq = the run's sequence number, stored last.
+struct HostGate
+{
+    int seq;
+    int active, maxdeg, overflow, item_overflow, sym;
+    long long total_edges;
+    long long class_items[kNumClasses];
+};
+
 struct SweepParams
 {
     const float *C;
@@ -51,7 +61,6 @@ struct SweepParams
     const int *off;
     const int *nbr;
     unsigned long long *best;  // MODE 0: lowest passing rank per CSR slot
-    int *rowfound;             // MODE 0: number of slots of the row that got a separating set
     unsigned long long *adj;   // live adjacency bitmap
     int *deg;                  // live degrees (decremented whenever an adjacency bit is cleared)
     int words;
@@ -77,19 +86,25 @@ struct FinalizeParams
     const int *off;
     const int *nbr;
     const unsigned long long *best;
-    const int *recoff;  // exclusive scan of rowfound
-    const long long *rec_base;  // [level] = records of all earlier levels
+    const unsigned *sel;  // level 1 after the row-streaming kernel: its 32-bit selection state instead of best
     int level;
     unsigned long long *adj;
     int *deg;
     int words;
     const unsigned long long *binom;
-    int *rec_x, *rec_y, *rec_l, *rec_s;  // rec_s is member-major: member a of record r at rec_s[a * rec_cap + r]
+    // Separating-set records live at the LEVEL-1 CSR slot of their ordered pair (a pair is removed at most once per
+    // run, so no placement scan is needed): slot of (X, Y) = off1[X] + rank of Y among X's neighbours after level 0 =
+    // off1[X] + wpre1[X, Y / 64] + popcount(adj0[X, Y / 64] below bit Y % 64).  rec_l = 0 marks an empty slot; the dense
+    // record list (and the winners' exact z) is produced when results are fetched (engine.hip: materialize_records).
+    const int *off1;
+    const int *wpre1;
+    const unsigned long long *adj0;
+    int *rec_x, *rec_y, *rec_l, *rec_s;  // rec_s is member-major: member a of slot r at rec_s[a * rec_cap + r]
     long long rec_cap;
-    float *rec_z;
     const int4 *meta;  // level 1 (row-streaming kernel ran): per CSR slot {Y, position of X in Y's list, off[Y], deg[Y]}
     const LevelCounters *cnt;  // this level's counters (gate)
     unsigned long long qcap;   // capacity of the level's recheck queue: an overflowed level is not finalised (it is redone)
+    unsigned long long *slots; // this level's spread counters ([2] = ordered pairs that received a separating set)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -172,7 +187,16 @@ __device__ __forceinline__ bool clear_edge(unsigned long long *adj, int *deg, in
 // sweep_exact.hip
 hipError_t launch_sweep_exact(int mode, bool het, int L, const SweepParams &p, int cls, hipStream_t st);
 hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipStream_t st);
-hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z);
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st);
+// dense record list -> exact Fisher z of every record of level L (result read-out)
+hipError_t launch_record_z(int L, const float *C, int n, const int *x, const int *y, const int *l, const int *s, long long stride,
+                           long long count, float *z, hipStream_t st);
+// sparse record store -> per-block counts / dense list (result read-out); blocks of kRecBlock slots
+constexpr int kRecBlock = 1024;
+hipError_t launch_rec_count(const int *rec_l, long long slots, int *counts, hipStream_t st);
+hipError_t launch_rec_compact(const int *rec_l, const int *rec_x, const int *rec_y, const int *rec_s, long long rec_cap,
+                              long long slots, const long long *block_off, int *out_x, int *out_y, int *out_l, int *out_s,
+                              long long out_stride, hipStream_t st);
 // sweep_fast.hip
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st);
 // sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
@@ -184,25 +208,36 @@ size_t sweep_vec_lds_bytes(int cls);
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st);
 hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
-hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int *wpre, const LevelCounters *cnt, hipStream_t st);
-// cnt = counters of level L; prev = counters of level L-1 (nullptr at level 1) with its recheck-queue capacity
-hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt,
-                       const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap, int shard_rank,
-                       int shard_world, hipStream_t st);
-// rowfound[row] = slots of the row whose best is set (after a cross-engine MIN of best, row-sharded runs)
-hipError_t launch_count_found(const int *off, const unsigned long long *best, int *rowfound, int n, hipStream_t st);
-hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, long long item_cap, const LevelCounters *cnt,
-                             hipStream_t st);
+hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int n, int words,
+                           int *wpre, const LevelCounters *cnt, hipStream_t st);
+// The level's plan from the degrees alone: CSR offsets, the work items of every degree class (written straight into the
+// class buffers), totals, and the level's gate.  cnt = counters of level L; prev = counters of level L-1 (nullptr at
+// level 1) with its recheck-queue capacity; gate / seq: pinned host record of the level; sym: level 0's asymmetry flag
+// (level 1 only, else nullptr).
+struct PlanArgs
+{
+    const int *deg;
+    int *off;
+    int2 *items[kNumClasses];
+    int n, L;
+    const unsigned long long *binom;
+    unsigned long long chunk;
+    int staged_classes, pair_mode;
+    LevelCounters *cnt;
+    const LevelCounters *prev;
+    unsigned long long prev_qcap;
+    long long item_cap;
+    int shard_rank, shard_world;
+    HostGate *gate;
+    int seq;
+    const int *sym;
+};
+hipError_t launch_plan(const PlanArgs &a, hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,
                                  hipStream_t st);
-hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, unsigned long long qcap,
-                           long long *rec_base, int level, hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, bool defer_count, hipStream_t st);
-hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st);
+                              int shard_world, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

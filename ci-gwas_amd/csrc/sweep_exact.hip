@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(kThreads) sweep_kernel(SweepParams p)
     }
     }  // work items
     __syncthreads();
-    flush_counters(s_cnt, p.slots, ntests, nsub, nrem, 0ull);
+    flush_counters(s_cnt, p.slots, ntests, nsub, MODE == 1 ? nrem : 0ull, 0ull);
 }
 
 template <int L, int MODE, bool HET>
@@ -200,9 +200,8 @@ __global__ void __launch_bounds__(kExactThreads) recheck_kernel(SweepParams p)
             bool first;
             if constexpr (MODE == 0)
             {
-                const unsigned long long old = atomicMin(&p.best[o0 + k2], en.rank);
-                first = (old == kNone);
-                if (first) atomicAdd(&p.rowfound[X], 1);
+                (void)atomicMin(&p.best[o0 + k2], en.rank);
+                first = false;  // Skeleton mode counts removals when it finalises the level
             }
             else
             {
@@ -241,105 +240,186 @@ hipError_t launch_recheck(int mode, bool het, int L, const SweepParams &p, hipSt
 }
 
 // ---------------------------------------------------------------------------
-// Skeleton mode: selected ranks -> sparse separating-set records, in two steps.
-//  gather_records_kernel (one wave per row, no heavy arithmetic): the record index is
-//    rec_base[level] + recoff[row] + (number of earlier selected slots of the row), so records
-//    are ordered by (level, X, position of Y) without atomics; writes x, y, level and the L
-//    members of S (member-major, so a level writes L dense streams) and clears the edge in both directions.
-//  record_z_kernel<L> (one lane per record of this level, count read on the device): the
-//    winner's Fisher z recomputed on the exact path, so pMax never depends on which lane won.
+// Skeleton mode: selected ranks -> separating-set records.
+//  gather_records_kernel (one wave per row, no heavy arithmetic): every slot with a selected rank writes x, y, level
+//    and the L members of S (member-major, so a level writes L dense streams) at the LEVEL-1 slot of its ordered pair
+//    (no placement scan, no atomics), and the row clears the removed edges from its bitmap row and sets its degree.
+//  The dense record list and the winners' Fisher z (recomputed on the exact path, so pMax never depends on which lane
+//  won) are produced when results are fetched: rec_count / rec_compact / record_z kernels below.
 // ---------------------------------------------------------------------------
 template <int L>
-__global__ void gather_records_kernel(FinalizeParams p)
+__global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
 {
+    __shared__ int s_found[4];
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    if (row >= p.n || !level_complete(p.cnt, p.qcap)) return;
-    const int o0 = p.off[row];
-    const int d = p.off[row + 1] - o0;
-    long long next = p.rec_base[p.level] + p.recoff[row];
-    int removed = 0;
-    for (int k0 = 0; k0 < d; k0 += 64)
+    if (!level_complete(p.cnt, p.qcap)) return;
+    int found = 0;
+    if (row < p.n)
     {
-        const int k = k0 + lane;
-        const bool valid = k < d;
-        const unsigned long long r = valid ? p.best[o0 + k] : kNone;
-        const int Y = valid ? p.nbr[o0 + k] : 0;
-        // The edge row - Y goes when EITHER side found a separating set.  Every wave only ever
-        // touches its own row of the bitmap and its own degree, so no returning atomics are needed:
-        // the other side's verdict is looked up (position of `row` in Y's ascending list).
-        bool gone = (r != kNone);
-        if (valid && !gone && p.meta != nullptr)
+        const int o0 = p.off[row];
+        const int d = p.off[row + 1] - o0;
+        int removed = 0;
+        for (int k0 = 0; k0 < d; k0 += 64)
         {
-            const int4 m = p.meta[o0 + k];
-            gone = (p.best[m.z + m.y] != kNone);
-        }
-        else if (valid && !gone)
-        {
-            const int oy = p.off[Y];
-            int lo = 0, hi = p.off[Y + 1] - oy;
-            while (lo < hi)
+            const int k = k0 + lane;
+            const bool valid = k < d;
+            unsigned long long r = kNone;
+            if (valid)
             {
-                const int mid = (lo + hi) >> 1;
-                if (p.nbr[oy + mid] < row)
-                    lo = mid + 1;
+                if (p.sel != nullptr)
+                {
+                    const unsigned v = p.sel[o0 + k];
+                    r = (v == 0xffffffffu) ? kNone : (unsigned long long)v;
+                }
                 else
-                    hi = mid;
+                    r = p.best[o0 + k];
             }
-            gone = (p.best[oy + lo] != kNone);  // adjacency is symmetric at level start: nbr[oy+lo] == row
-        }
-        // clear the bits: the wave owns this bitmap row, and the Y of a list ascend, so the lanes that share a
-        // 64-bit word are contiguous -> segmented OR over the wave, one plain read-modify-write per word
-        {
-            const int w = valid ? (Y >> 6) : -1 - lane;
-            unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1)
+            const int Y = valid ? p.nbr[o0 + k] : 0;
+            // The edge row - Y goes when EITHER side found a separating set.  Every wave only ever
+            // touches its own row of the bitmap and its own degree, so no returning atomics are needed:
+            // the other side's verdict is looked up (position of `row` in Y's ascending list).
+            bool gone = (r != kNone);
+            if (valid && !gone && p.meta != nullptr)
             {
-                const unsigned long long ob = __shfl_down(bits, o);
-                const int ow = __shfl_down(w, o);
-                if (lane + o < 64 && ow == w) bits |= ob;
+                const int4 m = p.meta[o0 + k];
+                gone = p.sel != nullptr ? (p.sel[m.z + m.y] != 0xffffffffu) : (p.best[m.z + m.y] != kNone);
             }
-            const int pw = __shfl_up(w, 1);
-            if (valid && bits != 0ull && (lane == 0 || pw != w)) p.adj[(size_t)row * p.words + w] &= ~bits;
-        }
-        removed += __popcll(__ballot(gone));
-        const unsigned long long has = __ballot(r != kNone);
-        if (has == 0ull) continue;
-        const long long slot = next + __popcll(has & ((1ull << lane) - 1ull));
-        next += __popcll(has);
-        if (r == kNone) continue;
-        int idx[L];
-        unrank_comb<L>(r, d, p.binom, idx);
-        p.rec_x[slot] = row;
-        p.rec_y[slot] = Y;
-        p.rec_l[slot] = L;
+            else if (valid && !gone)
+            {
+                const int oy = p.off[Y];
+                int lo = 0, hi = p.off[Y + 1] - oy;
+                while (lo < hi)
+                {
+                    const int mid = (lo + hi) >> 1;
+                    if (p.nbr[oy + mid] < row)
+                        lo = mid + 1;
+                    else
+                        hi = mid;
+                }
+                gone = (p.best[oy + lo] != kNone);  // adjacency is symmetric at level start: nbr[oy+lo] == row
+            }
+            // clear the bits: the wave owns this bitmap row, and the Y of a list ascend, so the lanes that share a
+            // 64-bit word are contiguous -> segmented OR over the wave, one plain read-modify-write per word
+            {
+                const int w = valid ? (Y >> 6) : -1 - lane;
+                unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
 #pragma unroll
-        for (int a = 0; a < L; a++) p.rec_s[(size_t)a * p.rec_cap + slot] = p.nbr[o0 + idx[a]];
+                for (int o = 1; o < 64; o <<= 1)
+                {
+                    const unsigned long long ob = __shfl_down(bits, o);
+                    const int ow = __shfl_down(w, o);
+                    if (lane + o < 64 && ow == w) bits |= ob;
+                }
+                const int pw = __shfl_up(w, 1);
+                if (valid && bits != 0ull && (lane == 0 || pw != w)) p.adj[(size_t)row * p.words + w] &= ~bits;
+            }
+            removed += __popcll(__ballot(gone));
+            found += __popcll(__ballot(r != kNone));
+            if (r == kNone) continue;
+            // the pair's level-1 slot (at level 1 that is the slot itself)
+            long long slot = (long long)o0 + k;
+            if constexpr (L > 1)
+            {
+                const size_t wi = (size_t)row * p.words + (Y >> 6);
+                slot = (long long)p.off1[row] + p.wpre1[wi] + __popcll(p.adj0[wi] & ((1ull << (Y & 63)) - 1ull));
+            }
+            int idx[L];
+            unrank_comb<L>(r, d, p.binom, idx);
+            p.rec_x[slot] = row;
+            p.rec_y[slot] = Y;
+            p.rec_l[slot] = L;
+#pragma unroll
+            for (int a = 0; a < L; a++) p.rec_s[(size_t)a * p.rec_cap + slot] = p.nbr[o0 + idx[a]];
+        }
+        if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
     }
-    if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
+    // cusk_stats.removed: ordered pairs that received a separating set at this level
+    if (lane == 0) s_found[threadIdx.x >> 6] = found;
+    __syncthreads();
+    if (threadIdx.x == 0)
+    {
+        const int t = s_found[0] + s_found[1] + s_found[2] + s_found[3];
+        if (t) atomicAdd(&p.slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+    }
+}
+
+// ---- result read-out: sparse record store -> dense list (ordered by level-1 slot = by (x, y)) -> exact z ----
+__global__ void __launch_bounds__(256) rec_count_kernel(const int *__restrict__ rec_l, long long slots, int *counts)
+{
+    __shared__ int s_c[4];
+    const long long base = (long long)blockIdx.x * kRecBlock;
+    int c = 0;
+    for (int i = threadIdx.x; i < kRecBlock; i += 256)
+        if (base + i < slots && rec_l[base + i] != 0) c++;
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+
+hipError_t launch_rec_count(const int *rec_l, long long slots, int *counts, hipStream_t st)
+{
+    if (slots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rec_count_kernel, dim3((unsigned)((slots + kRecBlock - 1) / kRecBlock)), dim3(256), 0, st, rec_l, slots, counts);
+    return hipGetLastError();
+}
+
+// one wave per block of kRecBlock slots, in slot order (ballot ranks): deterministic dense order
+__global__ void __launch_bounds__(64) rec_compact_kernel(const int *__restrict__ rec_l, const int *__restrict__ rec_x,
+                                                         const int *__restrict__ rec_y, const int *__restrict__ rec_s,
+                                                         long long rec_cap, long long slots, const long long *__restrict__ block_off,
+                                                         int *out_x, int *out_y, int *out_l, int *out_s, long long out_stride)
+{
+    const long long base = (long long)blockIdx.x * kRecBlock;
+    const int lane = threadIdx.x;
+    long long next = block_off[blockIdx.x];
+    for (int i0 = 0; i0 < kRecBlock; i0 += 64)
+    {
+        const long long sl = base + i0 + lane;
+        const int lv = (sl < slots) ? rec_l[sl] : 0;
+        const unsigned long long has = __ballot(lv != 0);
+        if (has == 0ull) continue;
+        const long long dst = next + __popcll(has & ((1ull << lane) - 1ull));
+        next += __popcll(has);
+        if (lv == 0) continue;
+        out_x[dst] = rec_x[sl];
+        out_y[dst] = rec_y[sl];
+        out_l[dst] = lv;
+        for (int a = 0; a < lv; a++) out_s[(size_t)a * out_stride + dst] = rec_s[(size_t)a * rec_cap + sl];
+    }
+}
+
+hipError_t launch_rec_compact(const int *rec_l, const int *rec_x, const int *rec_y, const int *rec_s, long long rec_cap,
+                              long long slots, const long long *block_off, int *out_x, int *out_y, int *out_l, int *out_s,
+                              long long out_stride, hipStream_t st)
+{
+    if (slots <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rec_compact_kernel, dim3((unsigned)((slots + kRecBlock - 1) / kRecBlock)), dim3(64), 0, st, rec_l, rec_x,
+                       rec_y, rec_s, rec_cap, slots, block_off, out_x, out_y, out_l, out_s, out_stride);
+    return hipGetLastError();
 }
 
 template <int L>
-__global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams p)
+__global__ void __launch_bounds__(kExactThreads) record_z_kernel(const float *__restrict__ C, int n, const int *__restrict__ rx,
+                                                                  const int *__restrict__ ry, const int *__restrict__ rl,
+                                                                  const int *__restrict__ rs, long long stride, long long count,
+                                                                  float *rz)
 {
     extern __shared__ __attribute__((aligned(16))) float ws_lds[];
-    if (!level_complete(p.cnt, p.qcap)) return;
-    const long long first = p.rec_base[p.level], count = p.rec_base[p.level + 1] - first;
-    const int n = p.n;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long long)gridDim.x * blockDim.x)
     {
-        const long long slot = first + i;
-        const int X = p.rec_x[slot], Y = p.rec_y[slot];
+        if (rl[i] != L) continue;
+        const int X = rx[i], Y = ry[i];
         int S[L];
 #pragma unroll
-        for (int a = 0; a < L; a++) S[a] = p.rec_s[(size_t)a * p.rec_cap + slot];
+        for (int a = 0; a < L; a++) S[a] = rs[(size_t)a * stride + i];
         float m2[(L > 1) ? L * L : 1], m1x[L], m1y[L];
 #pragma unroll
         for (int a = 0; a < L; a++)
         {
-            m1x[a] = p.C[(size_t)X * n + S[a]];
-            m1y[a] = p.C[(size_t)Y * n + S[a]];
+            m1x[a] = C[(size_t)X * n + S[a]];
+            m1y[a] = C[(size_t)Y * n + S[a]];
         }
         if constexpr (L >= 2)
         {
@@ -347,16 +427,37 @@ __global__ void __launch_bounds__(kExactThreads) record_z_kernel(FinalizeParams 
             for (int a = 0; a < L; a++)
 #pragma unroll
                 for (int b = 0; b < L; b++)
-                    m2[a * L + b] =
-                        (a == b) ? 1.0f : (a < b ? p.C[(size_t)S[a] * n + S[b]] : p.C[(size_t)S[b] * n + S[a]]);
+                    m2[a * L + b] = (a == b) ? 1.0f : (a < b ? C[(size_t)S[a] * n + S[b]] : C[(size_t)S[b] * n + S[a]]);
         }
         SubsetExact<L> cx;
         cx.prepare_ws(m2, m1x, ws_lds + threadIdx.x, kExactThreads);
-        const float rho = cx.rho(p.C[(size_t)X * n + Y], m1y);
+        const float rho = cx.rho(C[(size_t)X * n + Y], m1y);
         float z;
         (void)z_below<L == 1>(rho, 0.0f, &z);
-        p.rec_z[slot] = z;
+        rz[i] = z;
     }
+}
+
+hipError_t launch_record_z(int L, const float *C, int n, const int *x, const int *y, const int *l, const int *s, long long stride,
+                           long long count, float *z, hipStream_t st)
+{
+    if (count <= 0) return hipSuccess;
+    const dim3 zgrid((unsigned)std::min<long long>((count + kExactThreads - 1) / kExactThreads, 8192)), zblock(kExactThreads);
+    const size_t zlds = sizeof(float) * (size_t)exact_ws_floats(L) * kExactThreads;
+    switch (L)
+    {
+#define CUSK_CASE(LL)                                                                                     \
+    case LL:                                                                                              \
+        if (zlds > 64 * 1024)                                                                             \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(record_z_kernel<LL>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)zlds);             \
+        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, zblock, zlds, st, C, n, x, y, l, s, stride, count, z); \
+        break;
+        CUSK_FOR_LEVELS(CUSK_CASE)
+#undef CUSK_CASE
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
 }
 
 // records -> the ABI's [count x 14] layout, -1 beyond each record's level (result read-out, not on the hot path)
@@ -380,27 +481,13 @@ hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long r
     return hipGetLastError();
 }
 
-hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st, hipStream_t st_z, hipEvent_t ev_z)
+hipError_t launch_finalize(int L, const FinalizeParams &p, hipStream_t st)
 {
     const dim3 grid((p.n + 3) / 4), block(256);
-    // level 1 produces ~1e6 records on a 10k block, deeper levels a handful
-    const dim3 zgrid(L == 1 ? 8192 : 256), zblock(kExactThreads);
-    const size_t zlds = sizeof(float) * (size_t)exact_ws_floats(L) * kExactThreads;
     switch (L)
     {
-#define CUSK_CASE(LL)                                                          \
-    case LL:                                                                   \
-        hipLaunchKernelGGL(gather_records_kernel<LL>, grid, block, 0, st, p);  \
-        if (st_z != st)                                                        \
-        {                                                                      \
-            (void)hipEventRecord(ev_z, st);                                    \
-            (void)hipStreamWaitEvent(st_z, ev_z, 0);                           \
-        }                                                                      \
-        if (zlds > 64 * 1024)                                                      \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(record_z_kernel<LL>), \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)zlds); \
-        hipLaunchKernelGGL(record_z_kernel<LL>, zgrid, zblock, zlds, st_z, p);     \
-        break;
+#define CUSK_CASE(LL) \
+    case LL: hipLaunchKernelGGL(gather_records_kernel<LL>, grid, block, 0, st, p); break;
         CUSK_FOR_LEVELS(CUSK_CASE)
 #undef CUSK_CASE
         default: return hipErrorInvalidValue;

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     }
     }  // work items
     __syncthreads();
-    flush_counters(s_cnt, p.slots, ntests, nsub, nrem, nbad);
+    flush_counters(s_cnt, p.slots, ntests, nsub, MODE == 1 ? nrem : 0ull, nbad);
 }
 
 template <int L, int MODE, bool HET, bool VALIDATE>

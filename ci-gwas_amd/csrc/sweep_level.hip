@@ -313,8 +313,7 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
 
 // one wave per row: ascending neighbour indices, reset of the row's selection state
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
-                                unsigned long long *best, int *rowfound, int n, int words, int *wpre,
-                                const LevelCounters *cnt)
+                                unsigned long long *best, int n, int words, int *wpre, const LevelCounters *cnt)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -345,13 +344,12 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
         }
         run += __shfl(incl, 63);
     }
-    if (lane == 0 && rowfound) rowfound[row] = 0;
 }
 
-hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int *rowfound,
-                           int n, int words, int *wpre, const LevelCounters *cnt, hipStream_t st)
+hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int n, int words,
+                           int *wpre, const LevelCounters *cnt, hipStream_t st)
 {
-    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, rowfound, n, words, wpre, cnt);
+    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, n, words, wpre, cnt);
     return hipGetLastError();
 }
 
@@ -393,58 +391,67 @@ __device__ __forceinline__ long long prefix_256(const int *__restrict__ in, int 
     return pre + incl - v;
 }
 
-// The level's work plan, from the degrees alone (so it can run, and its counters travel to the host, before
-// the neighbour lists are even written): class and work-item count of every row, placement of the items inside
-// the class lists, level totals.  256 rows per workgroup: block-level exclusive scans of the rows' item counts (one
-// per class), then one atomicAdd per class and workgroup reserves the block's range (order between workgroups is
-// irrelevant: items of a class are independent).  class_items[] ends up holding the class totals.
-__global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, int *off, RowInfo *rowinfo, int n, int L,
-                                                     const unsigned long long *__restrict__ binom, unsigned long long chunk,
-                                                     int staged_classes, int pair_mode, LevelCounters *cnt,
-                                                     const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap,
-                                                     int shard_rank, int shard_world)
+// The level's work plan, from the degrees alone (so it runs before the neighbour lists are even written): CSR offsets,
+// class and work-item count of every row, the work items themselves (placed inside the class buffers by block scans +
+// one atomicAdd per class and workgroup; order between workgroups is irrelevant: items of a class are independent),
+// level totals, and the level's gate.  256 rows per workgroup.
+__global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
 {
     __shared__ int s_wave[kNumClasses][4];
     __shared__ long long s_base[kNumClasses];
     __shared__ long long s_red[8];
+    __shared__ int s_cls[256], s_nch[256], s_pos[256];
+    LevelCounters *cnt = a.cnt;
+    const int n = a.n, L = a.L;
     // the previous level did not run to completion (the loop ended there, or its recheck queue overflowed and it is
     // going to be redone): nothing of this level may touch the working sets; the gate stays closed (counters are zeroed
     // at run start)
-    if (prev != nullptr && !level_complete(prev, prev_qcap)) return;
+    if (a.prev != nullptr && !level_complete(a.prev, a.prev_qcap))
+    {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+        {
+            HostGate *g = a.gate;
+            g->active = 0;
+            g->maxdeg = 0;
+            g->overflow = 0;
+            g->item_overflow = 0;
+            g->sym = 0;
+            g->total_edges = 0;
+            for (int c = 0; c < kNumClasses; c++) g->class_items[c] = 0;
+            __threadfence_system();
+            *(volatile int *)&g->seq = a.seq;
+        }
+        return;
+    }
     const int row = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    RowInfo ri;
-    ri.cls = -1;
-    ri.base = 0;
-    ri.nchunks = 0;
-    ri.pad = 0;
-    const int d = (row < n) ? deg[row] : 0;
+    int cls = -1, nchunks = 0;
+    const int d = (row < n) ? a.deg[row] : 0;
     if (d > L)
     {
         // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
-        const unsigned long long nc = pair_mode ? (unsigned long long)d * (d - 1) / 2
-                                                : (L == 1 ? (unsigned long long)d : binom[(size_t)d * kBinomStride + L]);
+        const unsigned long long nc = a.pair_mode ? (unsigned long long)d * (d - 1) / 2
+                                                  : (L == 1 ? (unsigned long long)d : a.binom[(size_t)d * kBinomStride + L]);
         if (nc >= (1ull << 62))
             atomicOr(&cnt->overflow, 1);
-        else if (shard_world == 1 || row % shard_world == shard_rank)
+        else if (a.shard_world == 1 || row % a.shard_world == a.shard_rank)
         {  // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow check are global)
-            int cls = 0;
+            cls = 0;
             while (d > kClassCap[cls]) cls++;
-            if (cls >= staged_classes) cls = kNumClasses - 1;
-            ri.cls = cls;
-            ri.nchunks = (int)((nc + chunk - 1) / chunk);
+            if (cls >= a.staged_classes) cls = kNumClasses - 1;
+            nchunks = (int)((nc + a.chunk - 1) / a.chunk);
         }
     }
     // CSR offsets of the level (exclusive prefix of the degrees); the last workgroup knows the edge total
     {
         long long block_total;
-        const long long o0 = prefix_256(deg, n, d, s_red, &block_total);
-        if (row < n) off[row] = (int)o0;
+        const long long o0 = prefix_256(a.deg, n, d, s_red, &block_total);
+        if (row < n) a.off[row] = (int)o0;
         if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
         {
             const long long total = s_red[4] + s_red[5] + s_red[6] + s_red[7] + block_total;
-            off[n] = (int)total;
-            cnt->total_edges = total;
+            a.off[n] = (int)total;
+            __hip_atomic_store(&cnt->total_edges, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     // maximum degree: reduced over the workgroup first, one atomic per workgroup (same-address atomics from
@@ -465,7 +472,7 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
     {
-        const int mine = (ri.cls == c) ? ri.nchunks : 0;
+        const int mine = (cls == c) ? nchunks : 0;
         int v = mine;
         for (int o = 1; o < 64; o <<= 1)
         {
@@ -480,20 +487,40 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
     {
         const int c = threadIdx.x;
         const int tot = s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
-        s_base[c] = tot ? (long long)atomicAdd((unsigned long long *)&cnt->class_items[c], (unsigned long long)tot) : 0;
+        long long base = tot ? (long long)atomicAdd((unsigned long long *)&cnt->class_items[c], (unsigned long long)tot) : 0;
+        if (base + tot > a.item_cap) base = -1;  // would not fit: the gate stays closed, the host grows the buffers
+        s_base[c] = base;
     }
     __syncthreads();
-    if (row < n && ri.cls < 0) rowinfo[row] = ri;
-    if (row < n && ri.cls >= 0)
+    // the work items of the workgroup's rows, written cooperatively (a hub row has hundreds of them)
     {
-        int add = 0;
-        for (int w = 0; w < wave; w++) add += s_wave[ri.cls][w];
-        int e = 0;
+        int pos = -1;
+        if (cls >= 0 && s_base[cls] >= 0)
+        {
+            int add = 0;
+            for (int w = 0; w < wave; w++) add += s_wave[cls][w];
+            int e = 0;
 #pragma unroll
-        for (int c = 0; c < kNumClasses; c++)
-            if (ri.cls == c) e = excl[c];
-        ri.base = (int)s_base[ri.cls] + add + e;
-        rowinfo[row] = ri;
+            for (int c = 0; c < kNumClasses; c++)
+                if (cls == c) e = excl[c];
+            pos = (int)s_base[cls] + add + e;
+        }
+        s_cls[threadIdx.x] = (pos >= 0) ? cls : -1;
+        s_nch[threadIdx.x] = nchunks;
+        s_pos[threadIdx.x] = pos;
+        __syncthreads();
+        const int row0 = blockIdx.x * 256;
+        if (nchunks <= 1)
+        {  // the common case: every thread writes its own single item
+            if (pos >= 0 && nchunks == 1) a.items[cls][pos] = make_int2(row, 0);
+        }
+        for (int r = 0; r < 256; r++)
+        {
+            const int nch = s_nch[r];
+            if (nch <= 1 || s_cls[r] < 0) continue;
+            int2 *dst = a.items[s_cls[r]] + s_pos[r];
+            for (int c = threadIdx.x; c < nch; c += 256) dst[c] = make_int2(row0 + r, c);
+        }
     }
     // ---- the level's gate: the last workgroup to arrive sees every total (agent-scope loads: the other workgroups'
     // atomics were performed at the device's coherence point, not in this XCD's L2) ----
@@ -507,78 +534,33 @@ __global__ void __launch_bounds__(256) plan_kernel(const int *__restrict__ deg, 
             __threadfence();
             const int maxdeg = __hip_atomic_load(&cnt->maxdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int ovf = __hip_atomic_load(&cnt->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const long long edges = __hip_atomic_load(&cnt->total_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             bool fits = true;
+            HostGate *g = a.gate;
             for (int c = 0; c < kNumClasses; c++)
-                fits = fits && (__hip_atomic_load(&cnt->class_items[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) <= item_cap);
+            {
+                const long long ci = __hip_atomic_load(&cnt->class_items[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                fits = fits && (ci <= a.item_cap);
+                g->class_items[c] = ci;
+            }
+            const int active = (maxdeg - 1 >= L && ovf == 0 && fits) ? 1 : 0;
             cnt->item_overflow = fits ? 0 : 1;
-            cnt->active = (maxdeg - 1 >= L && ovf == 0 && fits) ? 1 : 0;
+            cnt->active = active;
+            g->active = active;
+            g->maxdeg = maxdeg;
+            g->overflow = ovf;
+            g->item_overflow = fits ? 0 : 1;
+            g->sym = a.sym ? *a.sym : 0;
+            g->total_edges = edges;
+            __threadfence_system();
+            *(volatile int *)&g->seq = a.seq;
         }
     }
 }
 
-hipError_t launch_plan(const int *deg, int *off, RowInfo *rowinfo, int n, int L, const unsigned long long *binom,
-                       unsigned long long chunk, int staged_classes, int pair_mode, LevelCounters *cnt,
-                       const LevelCounters *prev, unsigned long long prev_qcap, long long item_cap, int shard_rank,
-                       int shard_world, hipStream_t st)
+hipError_t launch_plan(const PlanArgs &a, hipStream_t st)
 {
-    hipLaunchKernelGGL(plan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, deg, off, rowinfo, n, L, binom, chunk,
-                       staged_classes, pair_mode, cnt, prev, prev_qcap, item_cap, shard_rank, shard_world);
-    return hipGetLastError();
-}
-
-struct ItemPtrs
-{
-    int2 *p[kNumClasses];
-};
-
-__global__ void fill_items_kernel(const RowInfo *__restrict__ rowinfo, int n, ItemPtrs ip, long long item_cap,
-                                  const LevelCounters *cnt)
-{
-    if (!cnt->active) return;  // also when the items would not fit: the host grows the buffers and resumes
-    const int row = blockIdx.x;
-    const RowInfo ri = rowinfo[row];
-    if (ri.cls < 0) return;
-    int2 *dst = ip.p[ri.cls];
-    for (int c = threadIdx.x; c < ri.nchunks; c += blockDim.x) dst[ri.base + c] = make_int2(row, c);
-    (void)item_cap;
-}
-
-hipError_t launch_fill_items(const RowInfo *rowinfo, int n, int2 *const *items, long long item_cap, const LevelCounters *cnt,
-                             hipStream_t st)
-{
-    ItemPtrs ip;
-    for (int c = 0; c < kNumClasses; c++) ip.p[c] = items[c];
-    hipLaunchKernelGGL(fill_items_kernel, dim3(n), dim3(64), 0, st, rowinfo, n, ip, item_cap, cnt);
-    return hipGetLastError();
-}
-
-// recoff = exclusive prefix of rowfound (256 rows per workgroup, prefix_256); level total; rec_base[level+1]
-__global__ void __launch_bounds__(256) rec_scan_kernel(const int *rowfound, int *recoff, int n, LevelCounters *cnt,
-                                                        unsigned long long qcap, long long *rec_base, int level)
-{
-    __shared__ long long s_red[8];
-    if (!level_complete(cnt, qcap))
-    {  // the level did not run (or is going to be redone on the exact path): it contributes no records
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) rec_base[level + 1] = rec_base[level];
-        return;
-    }
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    const int v = (row < n) ? rowfound[row] : 0;
-    long long block_total;
-    const long long e = prefix_256(rowfound, n, v, s_red, &block_total);
-    if (row < n) recoff[row] = (int)e;
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-    {
-        const long long total = s_red[4] + s_red[5] + s_red[6] + s_red[7] + block_total;
-        cnt->rec_total = (unsigned long long)total;
-        rec_base[level + 1] = rec_base[level] + total;
-    }
-}
-
-hipError_t launch_rec_scan(const int *rowfound, int *recoff, int n, LevelCounters *cnt, unsigned long long qcap,
-                           long long *rec_base, int level, hipStream_t st)
-{
-    hipLaunchKernelGGL(rec_scan_kernel, dim3((n + 255) / 256), dim3(256), 0, st, rowfound, recoff, n, cnt, qcap, rec_base, level);
+    hipLaunchKernelGGL(plan_kernel, dim3((a.n + 255) / 256), dim3(256), 0, st, a);
     return hipGetLastError();
 }
 
@@ -657,11 +639,7 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
             {
                 const unsigned long long old = atomicMin(&p.best[o0 + ky], (unsigned long long)ks);
                 atomicMin(&s_best[ky], (unsigned long long)ks);
-                if (old == kNone)
-                {
-                    nrem++;
-                    atomicAdd(&p.rowfound[X], 1);
-                }
+                if (old == kNone) nrem++;
             }
             else
             {
@@ -723,7 +701,7 @@ __global__ void __launch_bounds__(kThreads) level1_pair_kernel(SweepParams p)
     if ((tid & 63) == 0)
     {
         atomicAdd(&s_cnt[0], ntests);
-        atomicAdd(&s_cnt[2], nrem);
+        if (MODE == 1) atomicAdd(&s_cnt[2], nrem);  // Skeleton mode counts removals when it finalises the level
     }
     __syncthreads();
     if (tid == 0)
@@ -1107,42 +1085,6 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     }
 }
 
-// Skeleton mode, after the sweep: best = selected position per CSR slot in the engine's 64-bit form, rowfound[row]
-// = number of slots of the row that received a separating set; their total is the level's count of removed
-// directed edges
-__global__ void __launch_bounds__(256) level1_count_kernel(const int *__restrict__ off, const unsigned *__restrict__ sel,
-                                                           unsigned long long *best, int *rowfound, int n,
-                                                           unsigned long long *slots, const LevelCounters *cnt)
-{
-    __shared__ int s_sum[4];
-    if (!cnt->active) return;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    int c = 0;
-    if (row < n)
-    {
-        const int o0 = off[row], d = off[row + 1] - o0;
-        for (int k = lane; k < d; k += 64)
-        {
-            const unsigned v = sel[o0 + k];
-            best[o0 + k] = (v == kNone32) ? kNone : (unsigned long long)v;
-            c += (v != kNone32) ? 1 : 0;
-        }
-    }
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0)
-    {
-        if (row < n) rowfound[row] = c;
-        s_sum[threadIdx.x >> 6] = c;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0)
-    {
-        const int t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        if (t) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
-    }
-}
-
 // hetcor mode, after the sweep: every row drops the neighbours whose slot was marked (the wave owns its bitmap row:
 // word-aggregated plain read-modify-writes as in gather_records), sets its degree, and the removed directed edges
 // are counted
@@ -1189,35 +1131,9 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
     }
 }
 
-hipError_t launch_level1_count(const SweepParams &p, const unsigned *sel, hipStream_t st)
-{
-    hipLaunchKernelGGL(level1_count_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, p.n, p.slots,
-                       p.cnt);
-    return hipGetLastError();
-}
-
-__global__ void __launch_bounds__(256) count_found_kernel(const int *__restrict__ off, const unsigned long long *__restrict__ best,
-                                                          int *rowfound, int n)
-{
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (row >= n) return;
-    const int o0 = off[row], d = off[row + 1] - o0;
-    int c = 0;
-    for (int k = lane; k < d; k += 64) c += (best[o0 + k] != kNone) ? 1 : 0;
-    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (lane == 0) rowfound[row] = c;
-}
-
-hipError_t launch_count_found(const int *off, const unsigned long long *best, int *rowfound, int n, hipStream_t st)
-{
-    hipLaunchKernelGGL(count_found_kernel, dim3((n + 3) / 4), dim3(256), 0, st, off, best, rowfound, n);
-    return hipGetLastError();
-}
-
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, bool defer_count, hipStream_t st)
+                              int shard_world, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -1241,13 +1157,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     else
         hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
     if (ev_end) (void)hipEventRecord(ev_end, st);
-    if (mode == 0)
-    {
-        if (!defer_count)
-            hipLaunchKernelGGL(level1_count_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, sel, p.best, p.rowfound, n,
-                               p.slots, p.cnt);
-    }
-    else
+    if (mode != 0)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
                            p.words, p.slots, p.cnt);
     return hipGetLastError();

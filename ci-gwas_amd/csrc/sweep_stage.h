@@ -127,12 +127,7 @@ struct RowView
         {
             const unsigned long long old = atomicMin(&p.best[o0 + k2], rank);
             if constexpr (STAGED) atomicMin(&s_best[k2], rank);
-            if (old == kNone)
-            {
-                atomicAdd(&p.rowfound[X], 1);
-                return true;
-            }
-            return false;
+            return old == kNone;
         }
         else
         {

@@ -240,7 +240,6 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
                             const unsigned long long old = atomicMin(&p.best[o0 + k2], rank);
                             atomicMin(&s_rel[k2], myrel);
                             first = (old == kNone);
-                            if (first) atomicAdd(&p.rowfound[X], 1);
                         }
                         else
                         {
@@ -286,7 +285,7 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     {
         if (ntests) atomicAdd(&s_cnt[0], ntests);
         if (nsub) atomicAdd(&s_cnt[1], nsub);
-        if (nrem) atomicAdd(&s_cnt[2], nrem);
+        if (MODE == 1 && nrem) atomicAdd(&s_cnt[2], nrem);  // Skeleton mode counts removals when it finalises the level
     }
     __syncthreads();
     if (tid == 0)

@@ -120,7 +120,7 @@ const char *cusk_last_error(const cusk_engine *e);
  * classes and the winners' exact z run on an auxiliary stream), "corr_fp4" (default 1: the SNP x SNP contingency GEMMs of
  * cusk_corr_build on the FP4 matrix pipe; 0: the int8 MFMA form), "corr_popcount" (default 0; 1: bit-plane AND/popcount
  * cross-check kernels instead of the matrix cores), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
- * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
+ * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (default 1: per-level HIP events for kernel_ms / level_ms of cusk_stats; 0: only total_ms), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
  * cusk_sepselect_greedy for candidate lists too long for LDS, default 4 GiB; such pairs run in batches of what fits). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
@@ -172,9 +172,10 @@ int cusk_result_adj_i32(cusk_engine *e, int *G_host);
 int cusk_result_adj_i32_dev(cusk_engine *e, int *G_dev);
 int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_host);
 int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host /* n*n*14 */);
-/* sparse separation sets: one record per ordered pair with a non-empty set.
+/* sparse separation sets: one record per ordered pair with a non-empty set, ordered by (x, y).
  * Returns the count; arrays may be NULL to query it.  x,y: count ints;
- * level: count ints; z: count floats; S: count*14 ints (-1 padded). */
+ * level: count ints; z: count floats; S: count*14 ints (-1 padded).  The winners' Fisher z is computed on the first
+ * request that asks for it (z != NULL, or cusk_result_pmax) from the matrix of the run, which must still be resident. */
 long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *level, float *z, int *S);
 
 /* Correlation build on the device (a2-a5).  bed/phen/mean/std
