@@ -16,8 +16,10 @@ constexpr int kLevels = CUSK_ML + 2;  // per-level device records, index = level
 constexpr unsigned long long kNone = ~0ull;
 // degree classes of the level sweep: rows whose (d+1)^2 sub-matrix fits the class
 // capacity are staged in LDS; the last class reads C from global memory.
-constexpr int kNumClasses = 5;
-constexpr int kClassCap[kNumClasses] = {31, 63, 127, 191, 1 << 30};
+// (one class up to 63 neighbours: rows of that size are VGPR-limited, not LDS-limited, so a finer split only added a
+// launch and a stream fork per level)
+constexpr int kNumClasses = 4;
+constexpr int kClassCap[kNumClasses] = {63, 127, 191, 1 << 30};
 constexpr int kThreads = 256;
 constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many slots
 constexpr size_t kLdsLimit = 160 * 1024;

@@ -202,7 +202,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 may[c] = (c == kNumClasses - 1) && (pl.staged_classes == 0 || pl.maxdeg_bound > kClassCap[pl.staged_classes - 1]);
             nonempty += may[c];
         }
-        const bool fork = (nonempty > 1) && (e->opt_overlap != 0);
+        const bool fork = (nonempty > 1) && (e->opt_overlap != 0);  // (a stale degree bound forks for classes that turn out empty)
         if (fork)
         {
             CUSK_HIP(e, hipEventRecord(e->ev_fork, s));
@@ -341,7 +341,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (rc != CUSK_OK) return rc;
             rc = launch_level_finalize(redo);
             if (rc != CUSK_OK) return rc;
-            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
+            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
             redo = 0;
         }
         int enq_last = start - 1;
@@ -357,7 +357,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     if (!e->hgate[k].active) break;
                 }
             }
-            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
+            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
             LevelPlan &pl = plan[l];
             pl.redone = false;
             pl.known_items = false;
@@ -550,7 +550,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             }
             rc = launch_level_finalize(l);
             if (rc != CUSK_OK) return rc;
-            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
+            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
             enq_last = l;
         }
 
@@ -631,7 +631,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_main[0], e->ev_main[1]));
             local.main_kernel_ms[l] = ms;
         }
-        CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[l], e->ev_l1[l]));
+        // level time: plan to finaliser with timing = 2; otherwise from the end of the previous level's sweep to the
+        // end of this one's (the previous finaliser, this level's plan, lists and sweep)
+        if (e->opt_timing >= 2)
+            CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[l], e->ev_l1[l]));
+        else
+            CUSK_HIP(e, hipEventElapsedTime(&ms, l == 1 ? e->ev_l1[0] : e->ev_k1[l - 1], e->ev_k1[l]));
         local.level_ms[l] = ms;
     }
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_run[0], e->ev_run[1]));

@@ -401,6 +401,7 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
     __shared__ long long s_base[kNumClasses];
     __shared__ long long s_red[8];
     __shared__ int s_cls[256], s_nch[256], s_pos[256];
+    __shared__ unsigned long long s_big[4];
     LevelCounters *cnt = a.cnt;
     const int n = a.n, L = a.L;
     // the previous level did not run to completion (the loop ended there, or its recheck queue overflowed and it is
@@ -505,21 +506,31 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
                 if (cls == c) e = excl[c];
             pos = (int)s_base[cls] + add + e;
         }
-        s_cls[threadIdx.x] = (pos >= 0) ? cls : -1;
-        s_nch[threadIdx.x] = nchunks;
-        s_pos[threadIdx.x] = pos;
+        // rows with a single item write it themselves; the few rows with several (hubs: hundreds) are handled by the
+        // whole workgroup, found through ballots instead of a walk over all 256 rows
+        const bool big = (pos >= 0 && nchunks > 1);
+        if (pos >= 0 && nchunks == 1) a.items[cls][pos] = make_int2(row, 0);
+        const unsigned long long bm = __ballot(big);
+        if (lane == 0) s_big[wave] = bm;
+        if (big)
+        {
+            s_cls[threadIdx.x] = cls;
+            s_nch[threadIdx.x] = nchunks;
+            s_pos[threadIdx.x] = pos;
+        }
         __syncthreads();
         const int row0 = blockIdx.x * 256;
-        if (nchunks <= 1)
-        {  // the common case: every thread writes its own single item
-            if (pos >= 0 && nchunks == 1) a.items[cls][pos] = make_int2(row, 0);
-        }
-        for (int r = 0; r < 256; r++)
+        for (int w = 0; w < 4; w++)
         {
-            const int nch = s_nch[r];
-            if (nch <= 1 || s_cls[r] < 0) continue;
-            int2 *dst = a.items[s_cls[r]] + s_pos[r];
-            for (int c = threadIdx.x; c < nch; c += 256) dst[c] = make_int2(row0 + r, c);
+            unsigned long long m = s_big[w];
+            while (m)
+            {
+                const int r = w * 64 + __builtin_ctzll(m);
+                m &= m - 1;
+                const int nch = s_nch[r];
+                int2 *dst = a.items[s_cls[r]] + s_pos[r];
+                for (int c = threadIdx.x; c < nch; c += 256) dst[c] = make_int2(row0 + r, c);
+            }
         }
     }
     // ---- the level's gate: the last workgroup to arrive sees every total (agent-scope loads: the other workgroups'
