@@ -119,6 +119,7 @@ struct cusk_engine
     long long opt_chunk = 2048;
     long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
     int opt_lookahead = 2;
+    int opt_l1_exp = 0;                  // level-1 row kernel experiment bits (sweep_level.hip: RowsParams::exp)
     int opt_timing = 1;                  // per-level HIP events for cusk_stats' kernel_ms / level_ms (0: total only)               // levels the host may enqueue ahead of the counters it has seen
     long long opt_sep_ws_budget = 4ll << 30;  // HBM work space of cusk_sepselect_greedy for candidate lists beyond LDS
 

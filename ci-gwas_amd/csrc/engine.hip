@@ -107,7 +107,6 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     const bool het = (a.mode == 1 && a.Ness != nullptr);
     const int last_level = std::min(kML, a.maxlevel);
     const bool sharded = e->shard_world > 1;
-    if (sharded && a.mode != 0) return fail(e, CUSK_ERR_ARG, "row sharding supports Skeleton semantics only");
     if (sharded && !e->shard_fn) return fail(e, CUSK_ERR_ARG, "row sharding needs an exchange function");
 
     const size_t bm = sizeof(unsigned long long) * (size_t)n * words;
@@ -184,7 +183,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
                                            e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->opt_timing ? e->ev_main[0] : nullptr,
-                                           e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, s));
+                                           e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, e->opt_l1_exp, sharded, s));
             rows_timed = true;
             return CUSK_OK;
         }
@@ -264,8 +263,12 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             }
         }
         const size_t count = (size_t)e->hgate[l].total_edges;
-        const int elem = pl.use_rows ? 4 : 8;
-        void *dev = pl.use_rows ? e->sel.p : e->best[l & 1].p;
+        // Skeleton: the lowest passing rank per slot (64 bits; the row kernel's 32-bit form at level 1).  hetcor: one
+        // 32-bit mark per slot, 0 = the edge is gone (the row kernel leaves exactly that; the other kernels clear
+        // adjacency bits, which are turned into marks here): in both cases the join is an unsigned MIN
+        if (a.mode == 1 && !pl.use_rows) CUSK_HIP(e, launch_marks_from_bitmap(pl.sp, e->sel.as<unsigned>(), s));
+        const int elem = (pl.use_rows || a.mode == 1) ? 4 : 8;
+        void *dev = (pl.use_rows || a.mode == 1) ? e->sel.p : e->best[l & 1].p;
         int rc = 0;
         if (e->shard_host_staging)
         {
@@ -289,6 +292,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             rc = e->shard_fn(e->shard_user, l, dev, count, elem, 1, (void *)s);
         }
         if (rc != 0) return fail(e, CUSK_ERR_ARG, "row-shard exchange failed at level " + std::to_string(l));
+        // hetcor: every engine now drops the edges any engine removed (bitmap rows and degrees, identically everywhere)
+        if (a.mode == 1) CUSK_HIP(e, launch_level1_apply(pl.sp, e->sel.as<unsigned>(), false, s));
         return CUSK_OK;
     };
 
@@ -793,6 +798,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_lookahead = (int)value;
     else if (k == "timing")
         e->opt_timing = (int)value;
+    else if (k == "l1_exp")
+        e->opt_l1_exp = (int)value;
     else if (k == "sepselect_ws_bytes" && value > 0)
         e->opt_sep_ws_budget = value;
     else

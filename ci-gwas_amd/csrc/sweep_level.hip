@@ -805,6 +805,7 @@ struct RowsParams
     const int4 *meta;
     unsigned *sel;   // level-1 selection state per CSR slot: lowest passing position (Skeleton) / 0 = edge gone (hetcor)
     int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
+    int exp;         // experiment bits: 1 = selection state read past the XCD's L2 (sees other XCDs' minima), 2 = rows contiguous per XCD, 4 = count the atomics
     int shard_rank, shard_world;  // row-sharded runs: this engine streams the rows ya with ya % world == rank
 };
 
@@ -864,8 +865,14 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     __shared__ int s_pre[kRowsChunk + 1];
     __shared__ int s_wtot[2][kRowsThreads / 64];
     __shared__ unsigned long long s_cnt[4];
-    const int ya = blockIdx.x;
     const int n = p.n;
+    int ya = blockIdx.x;
+    if (rp.exp & 2)
+    {  // workgroups are dealt to the 8 XCDs round robin: give every XCD one contiguous band of rows
+        const int per = (n + 7) >> 3;
+        ya = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+        if (ya >= n) return;
+    }
     if (!p.cnt->active) return;
     const int o0 = p.off[ya];
     const int d = p.off[ya + 1] - o0;
@@ -878,7 +885,18 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     float mra = 0.0f;
     if (tid < d)
     {
-        m = rp.meta[o0 + tid];
+        // read once per (row, X): streamed past the caches (exp bit 8) so that the X lists every row of the band re-reads
+        // keep their place in L2
+        if (rp.exp & 8)
+        {
+            const int4 *mp = rp.meta + o0 + tid;
+            m.x = __builtin_nontemporal_load(&mp->x);
+            m.y = __builtin_nontemporal_load(&mp->y);
+            m.z = __builtin_nontemporal_load(&mp->z);
+            m.w = __builtin_nontemporal_load(&mp->w);
+        }
+        else
+            m = rp.meta[o0 + tid];
         mra = rp.rv[m.z + m.y];  // C[X, row]
     }
     const float *crow = p.C + (size_t)ya * n;
@@ -972,8 +990,16 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
             // 64-bit vector address arithmetic
             st.yb = ld32<int>(p.nbr, st.ib);
             st.rb = ld32<float>(rp.rv, st.ib);
-            st.selB = ld32<unsigned>(rp.sel, st.ib);
-            st.selA = ld32<unsigned>(rp.sel, st.ia);
+            if (rp.exp & 1)
+            {
+                st.selB = __hip_atomic_load(rp.sel + st.ib, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                st.selA = __hip_atomic_load(rp.sel + st.ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+                st.selB = ld32<unsigned>(rp.sel, st.ib);
+                st.selA = ld32<unsigned>(rp.sel, st.ia);
+            }
         };
         auto stage_b = [&](RowsStep &st) { st.c = ld32<float>(crow, (unsigned)st.yb); };
         auto stage_c = [&](const RowsStep &cur) {
@@ -1023,6 +1049,7 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
             const unsigned long long pa = __ballot(passA);
             const unsigned long long below = pa & ((1ull << lane) - 1ull) & ~((1ull << cur.first_lane) - 1ull);
             const bool headA = passA && (below == 0ull);
+            if (rp.exp & 4) nrem += (passB ? 1u : 0u) + (headA ? 1u : 0u);
             if constexpr (MODE == 0)
             {
                 // fire-and-forget minima: nobody waits for the L2 round trip; which slots got a separating
@@ -1138,13 +1165,46 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
     {
         const int t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
         // cusk_stats.removed: ordered pairs, as in Skeleton mode (both directions of an edge go)
-        if (t) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+        if (t && slots) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
     }
+}
+
+// hetcor mode, row-sharded runs: the sweeps of levels that do not use the row-streaming kernel clear adjacency bits
+// directly; turn the bitmap back into per-slot marks (0 = the edge is gone, all ones = alive) so that the engines can
+// join them with the same unsigned MIN as the Skeleton engine's selection state
+__global__ void __launch_bounds__(256) marks_from_bitmap_kernel(const int *__restrict__ off, const int *__restrict__ nbr,
+                                                                const unsigned long long *__restrict__ adj, unsigned *sel, int n,
+                                                                int words, const LevelCounters *cnt)
+{
+    if (!cnt->active) return;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int o0 = off[row], d = off[row + 1] - o0;
+    for (int k = lane; k < d; k += 64)
+    {
+        const int Y = nbr[o0 + k];
+        const bool alive = (adj[(size_t)row * words + (Y >> 6)] >> (Y & 63)) & 1ull;
+        sel[o0 + k] = alive ? kNone32 : 0u;
+    }
+}
+
+hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStream_t st)
+{
+    hipLaunchKernelGGL(marks_from_bitmap_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, p.adj, sel, p.n, p.words, p.cnt);
+    return hipGetLastError();
+}
+
+hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, bool count_removed, hipStream_t st)
+{
+    hipLaunchKernelGGL(level1_apply_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, p.n, p.words,
+                       count_removed ? p.slots : nullptr, p.cnt);
+    return hipGetLastError();
 }
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, hipStream_t st)
+                              int shard_world, int exp, bool defer_apply, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -1154,9 +1214,10 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.meta = static_cast<const int4 *>(meta);
     rp.sel = sel;
     rp.use_filter = use_filter ? 1 : 0;
+    rp.exp = exp;
     rp.shard_rank = shard_rank;
     rp.shard_world = shard_world;
-    const dim3 grid((unsigned)n);
+    const dim3 grid((unsigned)((exp & 2) ? ((n + 7) / 8) * 8 : n));
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     if (mode == 0 && !validate)
@@ -1168,7 +1229,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     else
         hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
     if (ev_end) (void)hipEventRecord(ev_end, st);
-    if (mode != 0)
+    if (mode != 0 && !defer_apply)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
                            p.words, p.slots, p.cnt);
     return hipGetLastError();

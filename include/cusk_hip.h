@@ -141,8 +141,9 @@ int cusk_engine_device(const cusk_engine *e); /* the HIP device ordinal the engi
  * derived identically on every engine, so all of them finish with the complete result (bit-identical to a
  * single-engine run).  host_staging = 1: `buf` is a pinned HOST copy (on_device = 0; for CPU collectives such as
  * gloo); 0: `buf` is the DEVICE buffer itself (on_device = 1; RCCL), the engine's stream is idle during the call and
- * the callee must have finished with the buffer when it returns.  world = 1 switches sharding off.  Skeleton
- * semantics only (cusk_run_hetcor refuses a sharded engine). */
+ * the callee must have finished with the buffer when it returns.  world = 1 switches sharding off.  cusk_run_hetcor
+ * shards the same way: what its engines join is one 32-bit mark per directed edge, 0 = removed at this level (elem_bytes
+ * 4 at every level), and the removal of the marked edges is then applied identically on every engine. */
 typedef int (*cusk_exchange_fn)(void *user, int level, void *buf, size_t count, int elem_bytes, int on_device, void *stream);
 int cusk_engine_set_row_shard(cusk_engine *e, int rank, int world, cusk_exchange_fn fn, void *user, int host_staging);
 

@@ -35,6 +35,21 @@ def test_row_sharded_engines_match_single_engine(extra):
     assert out["tests_all_ranks"] > 0
 
 
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("extra", [
+    ["--world", "2", "--oracle"],                                                   # Skeleton: adjacency + sepsets vs the oracle
+    ["--world", "2", "--engine", "hetcor", "--oracle"],                             # cuskss, uniform ESS, time index (row kernel at level 1)
+    ["--world", "3", "--engine", "het", "--oracle", "--markers", "1100", "--max-level", "3"],  # per-pair ESS (work-item kernels)
+    ["--world", "2", "--engine", "hetcor", "--oracle", "--option", "rows=0", "--markers", "900"],
+])
+def test_row_sharded_engines_match_the_oracle(extra):
+    """C3 is a cuskss config: the hetcor engine shards too (marks joined by the same unsigned MIN), and the sharded
+    results are checked against the oracle, not only against a single engine"""
+    out = run(*extra)
+    assert out["identical_to_oracle"] and out["identical_to_single_engine"], out
+    assert out["level"] >= 1 and out["tests_all_ranks"] > 0 and out["edges_final"] > 0
+
+
 @pytest.mark.timeout(600)
 def test_device_buffer_exchange_over_rccl_single_rank():
     """the on-device branch of the exchange (what one-rank-per-GPU runs use): D2D staging, sign-flip MIN over the

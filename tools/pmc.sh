@@ -3,7 +3,7 @@
 R=$PWD; PAT="$1"; shift; i=0
 for G in "$@"; do
   i=$((i+1)); rm -rf $R/gpurun_out/pmc$i
-  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $R/gpurun_out/pmc$i.log 2>&1) || { tail -5 $R/gpurun_out/pmc$i.log; exit 1; }
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 150 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $R/gpurun_out/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chromosome $BENCH_EXTRA > $R/gpurun_out/pmc$i.log 2>&1) || { tail -5 $R/gpurun_out/pmc$i.log; exit 1; }
   python3 - "$R/gpurun_out/pmc$i" "$PAT" <<'PY' | tee $R/gpurun_out/pmc_$i.txt
 import csv, glob, sys, collections
 d, pat = sys.argv[1], sys.argv[2]

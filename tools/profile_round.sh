@@ -12,7 +12,7 @@ grep '^{' $O/ss.log > $O/${TAG}_sepselect.json
 i=0
 for G in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   i=$((i+1))
-  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $O/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $O/pmc$i.log 2>&1)
+  (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --pmc $G --kernel-trace --output-format csv -d $O/pmc$i -o r -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chromosome > $O/pmc$i.log 2>&1)
 done
 python3 - "$O" "$TAG" <<'PY'
 import csv, glob, sys, collections, json
@@ -23,7 +23,7 @@ for f in glob.glob(O + "/pmc*/**/*counter_collection.csv", recursive=True):
         k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
         acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 with open(f"{O}/{TAG}_pmc_summary.txt", "w") as out:
-    out.write("rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline  (MI355X, three separate passes:\n"
+    out.write("rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chromosome  (MI355X, three separate passes:\n"
               "FETCH_SIZE | WRITE_SIZE | SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)\n"
               "per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them\n\n")
     last = None

@@ -64,14 +64,35 @@ def worker(args):
         return rc
 
     eng.set_row_shard(rank, world, exchange, host_staging=(args.backend != "nccl"))
-    eng.run_skeleton(Cd.ptr, n, Th, args.max_level)  # warm
+    # the hetcor engine (cuskss): uniform effective sample size, or per-pair sizes on the trait rows + a time index
+    th_het = cg.hetcor_threshold(args.alpha)
+    ti = np.zeros(n, np.int32)
+    ti[m:] = 1 + (np.arange(p) % 3)
+    Nh, Nd = None, None
+    if args.engine == "het":
+        rng = np.random.default_rng(args.seed)
+        Nh = np.full((n, n), float(N), np.float32)
+        ess = (rng.uniform(0.5, 1.0, (n, p)) * N).astype(np.float32)
+        Nh[:, m:] = ess
+        Nh[m:, :] = ess.T
+        Nh[m:, m:] = np.maximum(Nh[m:, m:], Nh[m:, m:].T)
+        Nd = cg.DeviceArray(Nh)
+
+    def run(e_):
+        if args.engine == "skeleton":
+            return e_.run_skeleton(Cd.ptr, n, Th, args.max_level)
+        if args.engine == "het":
+            return e_.run_hetcor(Cd.ptr, n, th_het, args.max_level, N_dev=Nd.ptr, time_index=ti)
+        return e_.run_hetcor(Cd.ptr, n, th_het, args.max_level, ess_uniform=float(N), time_index=ti)
+
+    run(eng)  # warm
     dist.barrier()
     t_ex[0] = 0.0
     t0 = time.perf_counter()
-    st = eng.run_skeleton(Cd.ptr, n, Th, args.max_level)
+    st = run(eng)
     t_sharded = time.perf_counter() - t0
     G = eng.adjacency()
-    rec = eng.sepsets()
+    rec = eng.sepsets() if args.engine == "skeleton" else None
     tests = torch.tensor([float(sum(st.tests))], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     dist.all_reduce(tests)
     out = None
@@ -80,29 +101,45 @@ def worker(args):
         for kv in args.option:
             k, v = kv.split("=")
             one.set_option(k, int(v))
-        one.run_skeleton(Cd.ptr, n, Th, args.max_level)
+        run(one)
         t0 = time.perf_counter()
-        st1 = one.run_skeleton(Cd.ptr, n, Th, args.max_level)
+        st1 = run(one)
         t_single = time.perf_counter() - t0
-        rec1 = one.sepsets()
 
         def canon(r):
             x, y, lv, z, S = r
             order = np.lexsort((y, x))
             return x[order], y[order], lv[order], z[order], S[order]
 
-        a, b = canon(rec), canon(rec1)
-        same = bool(np.array_equal(G, one.adjacency()) and st.level == st1.level and
-                    all(np.array_equal(u, v) for u, v in zip(a, b)))
-        out = {"workload": f"{m} SNPs x {p} traits, N={N}, l<={args.max_level}, one block on {world} engines",
+        same = bool(np.array_equal(G, one.adjacency()) and st.level == st1.level)
+        if args.engine == "skeleton":
+            a, b = canon(rec), canon(one.sepsets())
+            same = same and all(np.array_equal(u, v) for u, v in zip(a, b))
+        out = {"workload": f"{args.engine}: {m} SNPs x {p} traits, N={N}, l<={args.max_level}, one block on {world} engines",
                "backend": args.backend, "world": world, "identical_to_single_engine": same, "level": st.level,
-               "records": int(len(rec[0])), "tests_all_ranks": float(tests.item()), "tests_single": float(sum(st1.tests)),
-               "sharded_s": t_sharded, "exchange_s_rank0": t_ex[0], "single_engine_s": t_single,
-               "edges_level1": int(st.edges[1])}
+               "records": int(len(rec[0])) if rec is not None else 0, "tests_all_ranks": float(tests.item()),
+               "tests_single": float(sum(st1.tests)), "sharded_s": t_sharded, "exchange_s_rank0": t_ex[0],
+               "single_engine_s": t_single, "edges_level1": int(st.edges[1]), "edges_final": int(G.sum() // 2)}
+        if args.oracle:  # the sharded result against the CPU oracle (not only against another engine)
+            from oracle import oracle as O
+
+            if args.engine == "skeleton":
+                ref = O.skeleton(Cm, O.threshold_array(N, args.alpha), args.max_level)
+                x, y, lv, z, S = canon(rec)
+                rx, ry = np.nonzero(ref.sepset[:, :, 0] != -1)
+                ok = (np.array_equal(G, ref.G) and st.level == ref.level and np.array_equal(rx, x) and np.array_equal(ry, y)
+                      and np.array_equal(ref.sepset[rx, ry], S))
+            else:
+                Nref = Nh if Nh is not None else np.full((n, n), N, np.float32)
+                ref = O.hetcor_skeleton(Cm, np.ones((n, n), np.int32), Nref, O.hetcor_threshold(args.alpha), args.max_level, ti)
+                ok = np.array_equal(G, ref.G) and st.level == ref.level
+            out["identical_to_oracle"] = bool(ok)
+            same = same and bool(ok)
+            out["identical_to_single_engine"] = bool(out["identical_to_single_engine"])
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
-    return 0 if (out is None or out["identical_to_single_engine"]) else 1
+    return 0 if (out is None or (out["identical_to_single_engine"] and out.get("identical_to_oracle", True))) else 1
 
 
 def main():
@@ -116,6 +153,9 @@ def main():
     ap.add_argument("--alpha", type=float, default=1e-4)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE")
+    ap.add_argument("--engine", choices=["skeleton", "hetcor", "het"], default="skeleton",
+                    help="skeleton: cusk engine; hetcor: cuskss engine, uniform sample size + time index; het: per-pair sizes")
+    ap.add_argument("--oracle", action="store_true", help="also compare the sharded result with the CPU oracle")
     args = ap.parse_args()
     if "RANK" in os.environ:
         sys.exit(worker(args))
