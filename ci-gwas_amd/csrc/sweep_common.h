@@ -40,6 +40,9 @@ struct LevelCounters
     int item_overflow;         // a degree class has more work items than its buffer holds (host grows it and resumes)
     unsigned int done_blocks;  // plan_kernel workgroups that have finished (ticket of the last one)
     int pad;
+    // long levels (deep stage-two levels: millions of work items per class): workgroups of a persistent launch draw
+    // batches of items from here instead of taking a fixed stride, which evens out what early exits leave uneven
+    unsigned long long next_item[kNumClasses];
 };
 
 // What the host needs to know about a level to follow the device, written by the level's plan kernel straight into

@@ -25,10 +25,31 @@ __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L
     unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
     // persistent launch: the class's work items are counted on the device (sweep_common.h: level_items)
     const long long nitems = level_items(p);
-    for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
+    // Few items per workgroup: fixed stride (an atomic per item would cost more than it evens out).  Many (the deep
+    // levels of stage two run millions): batches drawn from a counter, so that workgroups whose items end early
+    // (every pair decided) take more of them.
+    constexpr long long kBatch = 8;
+    __shared__ long long s_next;
+    const bool dynamic = nitems > (long long)gridDim.x * 64;
+    long long it = dynamic ? 0 : (long long)blockIdx.x, batch_end = 0;
+    bool first = true;
+    for (;;)
     {
-    if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the staged copy
-    const int2 item = p.items[it];
+    if (dynamic && it >= batch_end)
+    {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (long long)atomicAdd(&p.cnt->next_item[p.cls], (unsigned long long)kBatch);
+        __syncthreads();
+        it = s_next;
+        batch_end = it + kBatch;
+        first = true;  // the barriers above already separate the items
+    }
+    if (it >= nitems) break;
+    if (!first) __syncthreads();  // the previous item's readers are done with the staged copy
+    first = false;
+    const long long it_cur = it;
+    it = dynamic ? it + 1 : it + gridDim.x;
+    const int2 item = p.items[it_cur];
     RowView<MODE, HET, STAGED> rv(p, item.x, smem);
     rv.stage();
     const int d = rv.d;
