@@ -195,11 +195,13 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tests = 0
+    canon = 0
     agg = {}
     for k in range(steps):
         allr, stats, owned = one_pass(k)
         for s in stats.values():
             tests += int(s.tests[0]) + int(s.tests[1])
+            canon += int(sum(s.stage[0].canonical_tests)) + int(sum(s.stage[1].canonical_tests))
             for key in ("ms_inputs", "ms_corr", "ms_stage1", "ms_prune", "ms_stage2", "ms_reduce"):
                 agg[key] = agg.get(key, 0.0) + float(getattr(s, key))
     torch.cuda.synchronize()
@@ -207,11 +209,11 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
         dist.barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt, float(tests)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        t = torch.tensor([dt, float(tests), float(canon)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tests = float(tmax[0].item()), float(t[1].item())
+        dt, tests, canon = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
     # per-level totals over this rank's blocks (last pass): which kernel dominates the device time
     lv_ms, lv_tests, lv_sub, nvar = np.zeros(15), np.zeros(15), np.zeros(15), 0
     for s in stats.values():
@@ -225,7 +227,8 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     res = {
         "blocks": len(sizes), "markers": int(sum(sizes)), "block_markers_min_mean_max": [int(min(sizes)), float(np.mean(sizes)), int(max(sizes))],
         "blocks_written": nwritten, "passes": steps, "ms_per_pass": dt / steps * 1e3, "blocks_per_sec": len(sizes) * steps / dt,
-        "ci_tests_per_sec": tests / dt, "ci_tests_per_pass": tests / steps,
+        "ci_tests_per_sec": canon / dt, "ci_tests_per_pass": canon / steps,
+        "executed_ci_tests_per_sec": tests / dt,
         "rank0_phase_ms_per_pass": {k[3:]: v / steps for k, v in agg.items()},
         "schedule": args.schedule, "inflight": args.inflight, "max_level": args.max_level, "max_level_two": args.max_level_two,
         "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); per-block files written by rank 0 inside the timed region",
@@ -234,7 +237,7 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     bs.close()
     if rank == 0:
         shutil.rmtree(workdir, ignore_errors=True)
-    return res, (lv_ms, lv_tests, lv_sub, nvar), dt, tests
+    return res, (lv_ms, lv_tests, lv_sub, nvar), dt, canon
 
 
 def main():
@@ -304,7 +307,8 @@ def main():
                                 f"(.bed -> correlations -> stage one -> prune -> stage two -> reduction -> gather -> files)",
                     "blocks_per_step": res["blocks"], "engine": "cusk", "parallelism": f"block-sharded x{world}, {args.schedule}",
                 },
-                "value_counts": "executed CI tests of both stages (the engine's device counters)",
+                "value_counts": "canonical CI tests of both stages (cusk_stats.canonical_tests: the sequential schedule, device counter); "
+                                "chromosome.executed_ci_tests_per_sec = what the parallel sweeps executed",
                 "blocks_per_sec": res["blocks_per_sec"],
                 "roofline": roofline_of(lv, lv_tests[lv], lv_sub[lv], nvar, lv_ms[lv], "cusk"),
                 "chromosome": res,
@@ -407,6 +411,7 @@ def main():
         },
         "value_counts": "executed CI tests (device counters)",
         "executed_tests_per_step": tests_total / K,
+        "canonical_tests_per_step_device": int(sum(st.canonical_tests)) if args.engine == "cusk" else None,
         "roofline": roofline_of(lv, st.tests[lv], st.subsets[lv], n, main_ms[lv], args.engine, traffic),
         "roofline_counts": "tests and conditioning sets the dominant kernel EXECUTED in one launch (device counters)",
         "level_rooflines": {str(l): {k: v for k, v in roofline_of(l, st.tests[l], st.subsets[l], n, main_ms[l], args.engine).items()
@@ -435,6 +440,20 @@ def main():
                           "total_incl_h2d": corr_ms[3]},
         "synth_gen_s": t_gen,
     }
+    if args.engine == "cusk" and sum(st.canonical_tests) > 0:
+        # `value` = canonical CI tests (the sequential schedule of the reference algorithm, computed on the device from
+        # the selected ranks and checked against the oracle's own count below) over the measured time
+        out["value_executed"] = out["value"]
+        out["value"] = float(sum(st.canonical_tests)) / (dt / K)
+        out["value_counts"] = ("canonical CI tests (sequential schedule; cusk_stats.canonical_tests, device counter) / measured time; "
+                               "value_executed = executed tests (device counters) / the same time")
+        # the dominant kernel's roofline on the CANONICAL tests of its level: the engine executes more tests than that
+        # (lanes cannot see each other's fresh verdicts; level 1 evaluates every pair), so this is the figure that cannot be
+        # inflated by doing needless work; roofline_executed = the same with the launch's own test counter
+        out["roofline_executed"] = out["roofline"]
+        out["roofline"] = roofline_of(lv, int(st.canonical_tests[lv]), int(st.subsets[lv]), n, main_ms[lv], args.engine, traffic)
+        out["roofline_counts"] = ("tests of the dominant kernel's level in the CANONICAL (sequential) schedule (device counter, equal to "
+                                  "the oracle's count: parity.canonical_count_equal); roofline_executed: the launch's own test counter")
     if not args.no_cpu_baseline:
         nall = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         from oracle import oracle as O
@@ -487,18 +506,14 @@ def main():
             # is the canonical count over the measured time, the rate of executed tests is reported beside it
             out["canonical_tests_per_step"] = int(ref.tests.sum())
             out["canonical_tests_by_level"] = [int(v) for v in ref.tests[: st.levels_run]]
-            # the dominant kernel's roofline on the CANONICAL work of its level (what the sequential reference schedule
-            # evaluates): the engine executes more tests than that (lanes cannot see each other's fresh verdicts; level 1
-            # evaluates every pair), so this is the figure that cannot be inflated by doing needless work
-            rc = roofline_of(lv, int(ref.tests[lv]), int(ref.subsets[lv]), n, main_ms[lv], args.engine, traffic)
-            out["roofline_executed"] = out["roofline"]
-            out["roofline"] = rc
-            out["roofline_counts"] = ("tests and conditioning sets of the dominant kernel's level in the CANONICAL (sequential) schedule, "
-                                      "counted by the oracle on this matrix; roofline_executed = the same with the launch's own counters")
-            out["value_executed"] = out["value"]
-            out["value"] = float(ref.tests.sum()) / (dt / K)
-            out["value_counts"] = ("canonical CI tests (the sequential schedule of the reference algorithm, counted by the oracle on "
-                                   "this very matrix) / measured time; value_executed = the engine's device counters / the same time")
+            if args.engine == "cusk":
+                par["canonical_count_equal"] = bool(int(sum(st.canonical_tests)) == int(ref.tests.sum()))
+                out["parity_ok"] = bool(out["parity_ok"] and par["canonical_count_equal"])
+            else:
+                out["value_executed"] = out["value"]
+                out["value"] = float(ref.tests.sum()) / (dt / K)
+                out["value_counts"] = ("canonical CI tests (counted by the oracle on this very matrix) / measured time; "
+                                       "value_executed = the engine's device counters / the same time")
         else:
             out["parity_checked"] = False
         base = {

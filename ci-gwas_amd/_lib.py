@@ -32,6 +32,7 @@ class CuskStats(C.Structure):
         ("violations", C.c_longlong),
         ("exact_fallbacks", C.c_longlong),
         ("main_kernel_ms", C.c_float * (ML + 1)),
+        ("canonical_tests", C.c_longlong * (ML + 1)),
     ]
 
 

@@ -93,6 +93,7 @@ struct cusk_engine
     cusk::LevelCounters *hcnt = nullptr;   // kLevels entries
     unsigned long long *hslots = nullptr;  // kLevels * kCounterSlots * 4
     long long *hrec_base = nullptr;        // kLevels + 1
+    unsigned long long *hcanon = nullptr;  // kLevels * kCounterSlots: canonical test counts
     int *hflag = nullptr;
     std::vector<unsigned long long> binom_host;
     long long binom_rows = 0;  // rows of the device-resident binomial table

@@ -74,7 +74,8 @@ struct RunArgs
 constexpr size_t kCtlCnt = 0;
 constexpr size_t kCtlSlots = (kCtlCnt + sizeof(LevelCounters) * kLevels + 15) & ~(size_t)15;
 constexpr size_t kCtlRecBase = (kCtlSlots + sizeof(unsigned long long) * kLevels * kCounterSlots * 4 + 15) & ~(size_t)15;
-constexpr size_t kCtlSym = (kCtlRecBase + sizeof(long long) * (kLevels + 1) + 15) & ~(size_t)15;
+constexpr size_t kCtlCanon = (kCtlRecBase + sizeof(long long) * (kLevels + 1) + 15) & ~(size_t)15;
+constexpr size_t kCtlSym = (kCtlCanon + sizeof(unsigned long long) * kLevels * kCounterSlots + 15) & ~(size_t)15;
 constexpr size_t kCtlBytes = kCtlSym + 16;
 
 struct LevelPlan
@@ -134,6 +135,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     LevelCounters *dcnt = reinterpret_cast<LevelCounters *>(ctl + ctl_cnt);
     unsigned long long *dslots = reinterpret_cast<unsigned long long *>(ctl + ctl_slots);
     (void)ctl_recbase;
+    unsigned long long *dcanon = reinterpret_cast<unsigned long long *>(ctl + kCtlCanon);
     int *dsym = reinterpret_cast<int *>(ctl + ctl_sym);
     CUSK_HIP(e, hipMemsetAsync(ctl, 0, ctl_bytes, s));
     if (a.mode == 1)
@@ -159,6 +161,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     local.max_degree[0] = n - 1;
     local.edges[0] = (long long)n * (n - 1);
     local.tests[0] = (long long)n * (n - 1) / 2;
+    local.canonical_tests[0] = a.mode == 0 ? local.tests[0] : 0;
     local.levels_run = 1;
 
     LevelPlan plan[kLevels];
@@ -543,6 +546,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             fp.cnt = dcnt + l;
             fp.qcap = qcap_gate[l];
             fp.slots = sp.slots;
+            fp.canon = dcanon + (size_t)l * kCounterSlots;
 
             if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
             int rc = launch_level_sweeps(l, false);
@@ -603,6 +607,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             CUSK_HIP(e, hipMemsetAsync(dcnt + start, 0, sizeof(LevelCounters) * (size_t)(kLevels - start), s));
             CUSK_HIP(e, hipMemsetAsync(dslots + (size_t)start * kCounterSlots * 4, 0,
                                        sizeof(unsigned long long) * (size_t)(kLevels - start) * kCounterSlots * 4, s));
+            CUSK_HIP(e, hipMemsetAsync(dcanon + (size_t)start * kCounterSlots, 0,
+                                       sizeof(unsigned long long) * (size_t)(kLevels - start) * kCounterSlots, s));
         }
     }
     // degrees and edge counts at the start of every level that was planned (the one at which the loop ended included)
@@ -625,6 +631,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             local.subsets[l] += (long long)sl[1];
             local.removed[l] += (long long)sl[2];
             local.violations += (long long)sl[3];
+            if (a.mode == 0) local.canonical_tests[l] += (long long)e->hcanon[(size_t)l * kCounterSlots + k];
         }
         local.rechecks[l] = (long long)e->hcnt[l].qcount;
         if (!timed) continue;
@@ -700,6 +707,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
             e->hcnt = reinterpret_cast<LevelCounters *>(hctl + kCtlCnt);
             e->hslots = reinterpret_cast<unsigned long long *>(hctl + kCtlSlots);
             e->hrec_base = reinterpret_cast<long long *>(hctl + kCtlRecBase);
+            e->hcanon = reinterpret_cast<unsigned long long *>(hctl + kCtlCanon);
         }
     }
     ok = ok && hipHostMalloc(reinterpret_cast<void **>(&e->hflag), sizeof(int)) == hipSuccess;

@@ -108,6 +108,7 @@ struct FinalizeParams
     const LevelCounters *cnt;  // this level's counters (gate)
     unsigned long long qcap;   // capacity of the level's recheck queue: an overflowed level is not finalised (it is redone)
     unsigned long long *slots; // this level's spread counters ([2] = ordered pairs that received a separating set)
+    unsigned long long *canon; // this level's kCounterSlots spread counters of CANONICAL tests (see gather_records_kernel)
 };
 
 __host__ __device__ inline size_t align16(size_t x) { return (x + 15) & ~(size_t)15; }
@@ -172,6 +173,42 @@ __device__ __forceinline__ void unrank_comb(unsigned long long rem, int d, const
         idx[i] = c;
         c++;
     }
+}
+
+// Number of L-combinations of d positions, in lexicographic order, up to and including S (ascending positions) that
+// CONTAIN position k.  Used to count the tests of the canonical (sequential) schedule: a slot k whose lowest passing set
+// has rank r was tested at the ranks 0..r whose set does not contain k, i.e. r + 1 - combos_upto_containing(S_r, k) times.
+// O(L) binomial look-ups (hockey-stick sums over the values a member can take below S[i]).
+template <int L>
+__device__ __forceinline__ unsigned long long combos_upto_containing(const int *S, int k, int d,
+                                                                       const unsigned long long *__restrict__ binom)
+{
+    auto C = [&](int a, int b) -> unsigned long long {
+        return (a < 0 || b < 0 || b > a) ? 0ull : binom[(size_t)a * kBinomStride + b];
+    };
+    unsigned long long cnt = 0;
+    bool in_prefix = false;  // k among S[0..i)
+    int prev = -1;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        const int lo = prev + 1, hi = S[i] - 1;  // values v < S[i] the i-th member can take behind the common prefix
+        const int t = L - i - 1;                 // members still to choose behind v
+        if (lo <= hi)
+        {
+            if (in_prefix)
+                cnt += C(d - lo, t + 1) - C(d - 1 - hi, t + 1);  // every completion: sum_v C(d-1-v, t)
+            else if (k > prev)
+            {
+                const int h2 = min(hi, k - 1);  // v < k: k is one of the t completions, sum_v C(d-2-v, t-1)
+                if (t >= 1 && lo <= h2) cnt += C(d - 1 - lo, t) - C(d - 2 - h2, t);
+                if (lo <= k && k <= hi) cnt += C(d - 1 - k, t);  // v == k
+            }
+        }
+        if (S[i] == k) in_prefix = true;
+        prev = S[i];
+    }
+    return cnt + (in_prefix ? 1ull : 0ull);
 }
 
 // clear the edge X - Y in both directions; every bit that this call flips lowers a degree once

@@ -251,15 +251,23 @@ template <int L>
 __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
 {
     __shared__ int s_found[4];
+    __shared__ unsigned long long s_canon[4];
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (!level_complete(p.cnt, p.qcap)) return;
     int found = 0;
+    // Tests of the canonical schedule (the reference algorithm run sequentially per row, as the oracle counts them): a
+    // slot is tested with every set up to its lowest passing one that does not contain it; a slot that is never
+    // separated with every set that does not contain it.  Independent of how many tests the parallel sweep executed.
+    unsigned long long canon = 0;
     if (row < p.n)
     {
         const int o0 = p.off[row];
         const int d = p.off[row + 1] - o0;
         int removed = 0;
+        // sets without a given member: C(d, L) - C(d - 1, L - 1) (0 for rows with fewer than L + 1 neighbours)
+        unsigned long long never = 0;
+        if (d > L) never = p.binom[(size_t)d * kBinomStride + L] - p.binom[(size_t)(d - 1) * kBinomStride + (L - 1)];
         for (int k0 = 0; k0 < d; k0 += 64)
         {
             const int k = k0 + lane;
@@ -316,6 +324,7 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
             }
             removed += __popcll(__ballot(gone));
             found += __popcll(__ballot(r != kNone));
+            if (valid && r == kNone) canon += never;
             if (r == kNone) continue;
             // the pair's level-1 slot (at level 1 that is the slot itself)
             long long slot = (long long)o0 + k;
@@ -326,6 +335,7 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
             }
             int idx[L];
             unrank_comb<L>(r, d, p.binom, idx);
+            canon += r + 1ull - combos_upto_containing<L>(idx, k, d, p.binom);
             p.rec_x[slot] = row;
             p.rec_y[slot] = Y;
             p.rec_l[slot] = L;
@@ -334,13 +344,20 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
         }
         if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
     }
-    // cusk_stats.removed: ordered pairs that received a separating set at this level
-    if (lane == 0) s_found[threadIdx.x >> 6] = found;
+    // cusk_stats.removed: ordered pairs that received a separating set at this level; cusk_stats.canonical_tests
+    for (int o = 32; o > 0; o >>= 1) canon += __shfl_xor(canon, o);
+    if (lane == 0)
+    {
+        s_found[threadIdx.x >> 6] = found;
+        s_canon[threadIdx.x >> 6] = canon;
+    }
     __syncthreads();
     if (threadIdx.x == 0)
     {
         const int t = s_found[0] + s_found[1] + s_found[2] + s_found[3];
         if (t) atomicAdd(&p.slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+        const unsigned long long c = s_canon[0] + s_canon[1] + s_canon[2] + s_canon[3];
+        if (c) atomicAdd(&p.canon[blockIdx.x & (kCounterSlots - 1)], c);
     }
 }
 

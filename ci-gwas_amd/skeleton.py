@@ -95,12 +95,13 @@ class Stats:
     violations: int
     exact_fallbacks: int
     main_kernel_ms: list
+    canonical_tests: list
 
     @staticmethod
     def of(s: CuskStats) -> "Stats":
         return Stats(s.level, s.levels_run, list(s.max_degree), list(s.edges), list(s.tests), list(s.subsets),
                      list(s.removed), list(s.kernel_ms), list(s.level_ms), float(s.total_ms), list(s.rechecks),
-                     int(s.violations), int(s.exact_fallbacks), list(s.main_kernel_ms))
+                     int(s.violations), int(s.exact_fallbacks), list(s.main_kernel_ms), list(s.canonical_tests))
 
 
 class DeviceArray:

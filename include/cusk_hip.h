@@ -104,6 +104,11 @@ typedef struct cusk_stats {
     long long exact_fallbacks;        /* levels redone entirely on the exact path (recheck queue overflow) */
     float main_kernel_ms[CUSK_ML + 1]; /* HIP-event time of the level's dominant kernel alone (level 1: the rows
                                          kernel without its prep / count passes; other levels = kernel_ms) */
+    long long canonical_tests[CUSK_ML + 1]; /* cusk_run_skeleton: CI tests of the CANONICAL schedule -- the reference
+                                         algorithm run sequentially per row: a neighbour is tested with every conditioning
+                                         set up to its lowest passing one -- computed on the device from
+                                         the selected ranks; `tests` counts what the parallel sweep executed (more: lanes
+                                         cannot see each other's fresh verdicts).  0 for cusk_run_hetcor. */
 } cusk_stats;
 
 /* device = HIP device ordinal; stream = a hipStream_t to run on, or NULL for a

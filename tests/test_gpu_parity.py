@@ -46,6 +46,8 @@ def _check_skeleton(cg, eng, oracle, Cm, Th, maxlevel):
     # the engine may evaluate more tests than the sequential schedule (parallel lanes), never fewer removals
     for l in range(1, ML + 1):
         assert st.tests[l] >= ref.tests[l] or st.tests[l] == 0 == ref.tests[l]
+    # ... and the device computes, from the selected ranks, exactly the number of tests the sequential schedule runs
+    assert list(st.canonical_tests[: ref.level + 1]) == [int(v) for v in ref.tests[: ref.level + 1]]
     Cd.free()
     return st, ref
 

@@ -3,7 +3,7 @@
 TAG=${1:-r01}; R=$PWD; O=$R/gpurun_out/$TAG; rm -rf $O; mkdir -p $O
 python3 -c "import torch" > /dev/null 2>&1
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1 && grep '^{' $O/bench.log > $O/${TAG}_bench.json
-(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/trace.log 2>&1)
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/trace.log 2>&1)
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats.csv
 # the sepselect path: kernel stats of one timing run, JSON line of the tool beside it
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss -o s -- python3 $R/tests/perf_sepselect.py --traits 80 --markers 8000 --sample-pairs 20 > $O/ss.log 2>&1)
