@@ -106,6 +106,7 @@ SYMBOLS = {
     "cusk_block_result_sep": (_vp, [_vp]),
     "cusk_block_result_write": (_i, [_vp, C.c_char_p]),
     "cusk_block_result_free": (None, [_vp]),
+    "cusk_engine_download": (_i, [_vp, _vp, _vp, _sz]),
     "cusk_dev_alloc": (_vp, [_sz]),
     "cusk_dev_free": (None, [_vp]),
     "cusk_dev_upload": (_i, [_vp, _vp, _sz]),

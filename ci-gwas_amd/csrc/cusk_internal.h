@@ -85,6 +85,7 @@ struct cusk_engine
     cusk::DevBuf den_x, den_y, den_l, den_z, den_s, den_counts, den_off;
     long long den_stride = 0;
     bool records_ready = false, z_ready = false;
+    cusk::DevBuf scratch_a, scratch_b;  // result read-out / gather scratch (no hipMalloc / hipFree per call)
     const float *last_C = nullptr;  // matrix of the last run (the winners' z is computed from it on request)
     int last_levels = 0;
     cusk::DevBuf rv, rpos, sel, wpre;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot

@@ -742,7 +742,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
                       &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_s, &e->den_x, &e->den_y, &e->den_l,
-                      &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->bed_dev, &e->phen_dev,
+                      &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->scratch_a, &e->scratch_b, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)
@@ -985,15 +985,23 @@ extern "C" int cusk_result_pmax(cusk_engine *e, const float *C_dev, float *pMax_
 // separating sets of all records in the ABI's [nrec x 14] layout
 static int records_to_host(cusk_engine *e, int *S_host)
 {
-    int *tmp = nullptr;
+    // engine-owned scratch: hipMalloc / hipFree per call would synchronise the whole device (several engines share it)
     const size_t bytes = sizeof(int) * kML * (size_t)e->nrec;
-    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&tmp), bytes));
+    CUSK_HIP(e, e->scratch_a.ensure(bytes));
+    int *tmp = e->scratch_a.as<int>();
     hipError_t st = launch_expand_records(e->den_s.as<int>(), e->den_l.as<int>(), e->den_stride, e->nrec, tmp, e->stream);
     if (st == hipSuccess) st = hipMemcpyAsync(S_host, tmp, bytes, hipMemcpyDeviceToHost, e->stream);
     if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
-    (void)hipFree(tmp);
     if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
     return CUSK_OK;
+}
+
+// device -> host on the engine's stream (waits for that stream only)
+static hipError_t fetch(cusk_engine *e, void *dst, const void *src, size_t bytes)
+{
+    hipError_t st = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    return st;
 }
 
 extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
@@ -1008,8 +1016,8 @@ extern "C" int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host)
     if (e->nrec > 0)
     {
         std::vector<int> x(e->nrec), y(e->nrec), S((size_t)e->nrec * kML);
-        CUSK_HIP(e, hipMemcpy(x.data(), e->den_x.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
-        CUSK_HIP(e, hipMemcpy(y.data(), e->den_y.p, sizeof(int) * e->nrec, hipMemcpyDeviceToHost));
+        CUSK_HIP(e, fetch(e, x.data(), e->den_x.p, sizeof(int) * e->nrec));
+        CUSK_HIP(e, fetch(e, y.data(), e->den_y.p, sizeof(int) * e->nrec));
         rc = records_to_host(e, S.data());
         if (rc != CUSK_OK) return rc;
         for (long long r = 0; r < e->nrec; r++)
@@ -1026,10 +1034,10 @@ extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *le
     const long long c = e->nrec;
     if (c > 0)
     {
-        if (x && hipMemcpy(x, e->den_x.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (y && hipMemcpy(y, e->den_y.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (level && hipMemcpy(level, e->den_l.p, sizeof(int) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-        if (z && hipMemcpy(z, e->den_z.p, sizeof(float) * c, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+        if (x && fetch(e, x, e->den_x.p, sizeof(int) * c) != hipSuccess) return -1;
+        if (y && fetch(e, y, e->den_y.p, sizeof(int) * c) != hipSuccess) return -1;
+        if (level && fetch(e, level, e->den_l.p, sizeof(int) * c) != hipSuccess) return -1;
+        if (z && fetch(e, z, e->den_z.p, sizeof(float) * c) != hipSuccess) return -1;
         if (S && records_to_host(e, S) != CUSK_OK) return -1;
     }
     return c;
@@ -1039,17 +1047,15 @@ extern "C" int cusk_gather_submatrix(cusk_engine *e, const float *M_dev, int n, 
 {
     if (!e || !M_dev || !idx_host || !out_host || k <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
     CUSK_HIP(e, hipSetDevice(e->device));
-    int *idx_d = nullptr;
-    float *out_d = nullptr;
-    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&idx_d), sizeof(int) * (size_t)k));
-    hipError_t st = hipMalloc(reinterpret_cast<void **>(&out_d), sizeof(float) * (size_t)k * k);
-    if (st == hipSuccess) st = hipMemcpyAsync(idx_d, idx_host, sizeof(int) * (size_t)k, hipMemcpyHostToDevice, e->stream);
+    CUSK_HIP(e, e->scratch_a.ensure(sizeof(int) * (size_t)k));
+    CUSK_HIP(e, e->scratch_b.ensure(sizeof(float) * (size_t)k * k));
+    int *idx_d = e->scratch_a.as<int>();
+    float *out_d = e->scratch_b.as<float>();
+    hipError_t st = hipMemcpyAsync(idx_d, idx_host, sizeof(int) * (size_t)k, hipMemcpyHostToDevice, e->stream);
     if (st == hipSuccess) st = launch_gather_sub(M_dev, n, idx_d, k, out_d, e->stream);
     if (st == hipSuccess)
         st = hipMemcpyAsync(out_host, out_d, sizeof(float) * (size_t)k * k, hipMemcpyDeviceToHost, e->stream);
     if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
-    (void)hipFree(idx_d);
-    (void)hipFree(out_d);
     if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
     return CUSK_OK;
 }
@@ -1058,13 +1064,22 @@ extern "C" int cusk_gather_submatrix_dev(cusk_engine *e, const float *M_dev, int
 {
     if (!e || !M_dev || !idx_host || !out_dev || k <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
     CUSK_HIP(e, hipSetDevice(e->device));
-    int *idx_d = nullptr;
-    CUSK_HIP(e, hipMalloc(reinterpret_cast<void **>(&idx_d), sizeof(int) * (size_t)k));
+    CUSK_HIP(e, e->scratch_a.ensure(sizeof(int) * (size_t)k));
+    int *idx_d = e->scratch_a.as<int>();
     hipError_t st = hipMemcpyAsync(idx_d, idx_host, sizeof(int) * (size_t)k, hipMemcpyHostToDevice, e->stream);
     if (st == hipSuccess) st = launch_gather_sub(M_dev, n, idx_d, k, out_dev, e->stream);
-    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
-    (void)hipFree(idx_d);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);  // idx_host may go away; the next run reuses the scratch
     if (st != hipSuccess) return fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+    return CUSK_OK;
+}
+
+// device -> host copy ordered after the engine's work and waiting for the engine's stream only (cusk_dev_download is a
+// device-wide blocking copy: with several engines on one GPU it serialises them)
+extern "C" int cusk_engine_download(cusk_engine *e, void *dst_host, const void *src_dev, size_t bytes)
+{
+    if (!e || !dst_host || !src_dev) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    CUSK_HIP(e, fetch(e, dst_host, src_dev, bytes));
     return CUSK_OK;
 }
 

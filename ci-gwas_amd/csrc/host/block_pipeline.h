@@ -51,7 +51,7 @@ inline Bits fetch_adjacency(cusk_engine *e)
     b.n = cusk_result_n(e);
     b.words = cusk_result_words(e);
     b.w.resize((size_t)b.n * b.words);
-    if (cusk_dev_download(b.w.data(), cusk_result_adj_bits_dev(e), b.w.size() * sizeof(uint64_t)) != CUSK_OK)
+    if (cusk_engine_download(e, b.w.data(), cusk_result_adj_bits_dev(e), b.w.size() * sizeof(uint64_t)) != CUSK_OK)
         engine_die("adjacency download", e);
     return b;
 }

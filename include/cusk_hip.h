@@ -293,6 +293,9 @@ const int *cusk_block_result_sep(const cusk_block_result *r);    /* num_var^2 * 
 int cusk_block_result_write(const cusk_block_result *r, const char *outdir);
 void cusk_block_result_free(cusk_block_result *r);
 
+/* device -> host copy ordered after the engine's work; waits for the engine's stream only */
+int cusk_engine_download(cusk_engine *e, void *dst_host, const void *src_dev, size_t bytes);
+
 /* device memory helpers so that C hosts need no HIP headers */
 void *cusk_dev_alloc(size_t bytes);
 void cusk_dev_free(void *p);
