@@ -376,3 +376,37 @@ def test_randomised_stress_against_oracle(cg, eng, oracle, synth):
         checked_levels += st.levels_run
         Cd.free()
     assert checked_levels > 300
+
+
+@pytest.mark.parametrize("opts", [
+    {"lookahead": 0}, {"lookahead": 3}, {"timing": 0}, {"timing": 2},
+    {"item_capacity": 1024},                      # more work items than the buffers hold: grown, level taken up again
+    {"item_capacity": 1024, "queue_capacity": 16, "lookahead": 2},  # both resume paths in one run
+    {"item_capacity": 1024, "rows": 0},           # ... with the pair kernel's work items at level 1
+])
+def test_enqueue_ahead_loop_options_and_resume_paths(cg, oracle, synth, opts):
+    """the level loop runs ahead of the device; whatever the distance, the timing mode, or how often a level has to be
+    taken up again (work-item buffers too small, recheck queue overflow), the result is the oracle's"""
+    Cm = synth.synth_corr_block(1400, 8, N=8192, block_index=21)
+    Th = cg.threshold_array(8192, 1e-4)
+    e = cg.Engine(0)
+    for k, v in opts.items():
+        e.set_option(k, v)
+    st, ref = _check_skeleton(cg, e, oracle, Cm, Th, 5)
+    assert st.levels_run == ref.level and sum(st.tests) > 0
+    if "queue_capacity" in opts:
+        assert st.exact_fallbacks >= 1
+    # a second run on the same engine (buffers grown, gate records of the previous run in place) gives the same
+    st2, _ = _check_skeleton(cg, e, oracle, Cm, Th, 5)
+    assert st2.canonical_tests == st.canonical_tests
+    # the hetcor engine through the same loop
+    th = cg.hetcor_threshold(1e-4)
+    Cd = cg.DeviceArray(Cm)
+    n = Cm.shape[0]
+    ti = np.zeros(n, np.int32)
+    ti[1400:] = 1
+    sth = e.run_hetcor(Cd.ptr, n, th, 4, ess_uniform=8192.0, time_index=ti)
+    refh = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), 8192, np.float32), th, 4, ti)
+    assert np.array_equal(e.adjacency(), refh.G) and sth.level == refh.level
+    Cd.free()
+    e.close()
