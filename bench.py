@@ -436,6 +436,7 @@ def main():
             for l in range(st.levels_run)
         },
         "blocks_per_sec": K / dt,
+        "filter_violations": int(st.violations), "exact_fallbacks": int(st.exact_fallbacks),
         "corr_build_ms": {"decode": corr_ms[0], "snp_x_snp": corr_ms[1], "snp_trait_and_trait_trait": corr_ms[2],
                           "total_incl_h2d": corr_ms[3]},
         "synth_gen_s": t_gen,

@@ -410,10 +410,10 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 maxdeg1 = e->hgate[1].maxdeg;
                 for (int k = 0; k < 2; k++)
                 {
-                    CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * (size_t)cap_edges));
+                    CUSK_HIP(e, e->nbr[k].ensure(sizeof(int) * ((size_t)cap_edges + 4)));  // + room: the row kernel's 8-byte requests
                     if (a.mode == 0) CUSK_HIP(e, e->best[k].ensure(sizeof(unsigned long long) * (size_t)cap_edges));
                 }
-                CUSK_HIP(e, e->rv.ensure(sizeof(float) * (size_t)cap_edges));
+                CUSK_HIP(e, e->rv.ensure(sizeof(float) * ((size_t)cap_edges + 4)));
                 CUSK_HIP(e, e->rpos.ensure(sizeof(int) * 4 * (size_t)cap_edges));
                 CUSK_HIP(e, e->sel.ensure(sizeof(unsigned) * (size_t)cap_edges));
                 if (a.mode == 0)

@@ -805,6 +805,7 @@ struct RowsParams
     const int4 *meta;
     unsigned *sel;   // level-1 selection state per CSR slot: lowest passing position (Skeleton) / 0 = edge gone (hetcor)
     int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
+    float beta;      // half-width of the level-1 guard band on rho^2 (level1_beta)
     int exp;         // experiment bits: 2 = rows contiguous per XCD, 4 = count the atomics, 8 = non-temporal meta loads
     int shard_rank, shard_world;  // row-sharded runs: this engine streams the rows ya with ya % world == rank
 };
@@ -812,17 +813,30 @@ struct RowsParams
 constexpr int kRowsThreads = 256;
 constexpr int kRowsChunk = 256;    // neighbours X of the row handled per staging round
 
+// Half-width of the level-1 guard band on rho^2.  Unlike the deeper levels (Cholesky against SVD, conditioning-dependent:
+// kBeta) the two forms of the level-1 test share their operands, so the band only has to cover rounding: the exact form's
+// rho carries <= 4 roundings (2.4e-7 relative), its Fisher z (two correctly rounded logs of 1 +- rho) <= 5.6e-8 absolute,
+// i.e. <= 5.6e-8 / t relative in rho at the decision point |rho| = t = tanh(th); the squared form adds <= 5 roundings
+// (3e-7 relative on rho^2).  Sixteen times that sum, never more than kBeta: 7.6e-5 at the headline threshold
+// (t = 0.0304) instead of 2e-3 -- with the wide band a quarter of all 256-test wave steps had a lane in the band and
+// went through the exact form (division, two square roots, log), which was 40 % of the kernel's vector instructions.
+inline float level1_beta(float t2)
+{
+    const double t = std::sqrt(std::max((double)t2, 1e-30));
+    return (float)std::min((double)kBeta, 16.0 * (2.0 * (2.4e-7 + 5.6e-8 / t) + 3.0e-7));
+}
+
 // Level-1 test, rho = h01 / (sqrt|h00| sqrt|hc|) against th, in the squared form with the guard band of
-// ci_fast.h.  It starts from the SAME fp32 h00, h01, hc as the reference's form (identical operations), so
+// ci_fast.h (level1_beta wide).  It starts from the SAME fp32 h00, h01, hc as the reference's form (identical operations), so
 // unlike the deeper levels no conditioning margin is needed: the two differ by a few ulp whatever the
 // operands are, as long as they are positive.  Returns pass; sure = false (inside the band, operand <= 0, NaN,
 // filter off) sends the lane to level1_exact.
-__device__ __forceinline__ bool level1_filter(float h00, float h01, float hc, float t2, bool ok, bool &sure)
+__device__ __forceinline__ bool level1_filter(float h00, float h01, float hc, float t2, float beta, bool ok, bool &sure)
 {
     const float lhs = h01 * h01;
     const float rhs = t2 * (h00 * hc);
-    const bool pass = lhs < rhs * (1.0f - kBeta);
-    const bool fail = lhs > rhs * (1.0f + kBeta);
+    const bool pass = lhs < rhs * (1.0f - beta);
+    const bool fail = lhs > rhs * (1.0f + beta);
     sure = ok && (h00 > 0.0f) && (pass || fail);
     return pass;
 }
@@ -902,7 +916,7 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     [[maybe_unused]] int tiA = 0;
     if constexpr (MODE == 1) tiA = p.time_index[ya];
     const bool use_filter = rp.use_filter != 0;
-    const float th = p.th, t2 = p.t2;
+    const float th = p.th, t2 = p.t2, beta = rp.beta;
     unsigned ntests = 0, nrem = 0, viol = 0;
     for (int kc = 0; kc < d; kc += kRowsChunk)
     {
@@ -1015,8 +1029,8 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
             const float h00b = 1.0f - (ra * ra), h01b = rb - (ra * c);
             const bool ok = use_filter && (hc > 0.0f);
             bool sureA, sureB;
-            bool passA = level1_filter(h00a, h01a, hc, t2, ok, sureA);
-            bool passB = level1_filter(h00b, h01b, hc, t2, ok, sureB);
+            bool passA = level1_filter(h00a, h01a, hc, t2, beta, ok, sureA);
+            bool passB = level1_filter(h00b, h01b, hc, t2, beta, ok, sureB);
             ntests += (needA ? 1u : 0u) + (needB ? 1u : 0u);
             const bool slowA = needA && (VALIDATE || !sureA), slowB = needB && (VALIDATE || !sureB);
             if (__ballot(slowA || slowB) != 0ull)
@@ -1096,6 +1110,312 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
     for (int o = 32; o > 0; o >>= 1)
     {
         ntests += __shfl_xor(ntests, o);  // < 2^32 per wave: 64 lanes x (work of a quarter row)
+        nrem += __shfl_xor(nrem, o);
+        if (VALIDATE) viol += __shfl_xor(viol, o);
+    }
+    if (lane == 0)
+    {
+        if (ntests) atomicAdd(&s_cnt[0], (unsigned long long)ntests);
+        if (nrem) atomicAdd(&s_cnt[2], (unsigned long long)nrem);
+        if (VALIDATE && viol) atomicAdd(&s_cnt[3], (unsigned long long)viol);
+    }
+    __syncthreads();
+    if (tid == 0)
+    {
+        unsigned long long *sl = p.slots + (size_t)(blockIdx.x & (kCounterSlots - 1)) * 4;
+        if (s_cnt[0]) atomicAdd(&sl[0], s_cnt[0]);
+        if (s_cnt[2]) atomicAdd(&sl[2], s_cnt[2]);
+        if (s_cnt[3]) atomicAdd(&sl[3], s_cnt[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same sweep with TWO consecutive list positions per lane (round 2).  The one-position form above is bound by
+// vector-instruction issue, not by memory (136 vector instructions per 64 pairs, 67 % of the SIMDs' issue cycles at
+// 0.40 ms on the 10k block; staging the row of C in LDS instead of gathering it through L1/L2 made it slower), and
+// two thirds of those instructions are bookkeeping of the flattened iteration space that does not depend on how many
+// positions a lane carries: the walk over the segment prefix array, slot arithmetic, segment-head detection, loop
+// control.  Here the flat range counts PAIRS of positions (b, b + 1) of a segment (odd segments are padded by one masked
+// position, so a pair never straddles two segments); a lane requests both list entries with one 8-byte load each
+// (nbr, rv: 4-byte aligned dwordx2), gathers two elements of the row of C, and evaluates its four tests as float2
+// pairs (v_pk_mul_f32 / v_pk_add_f32): the same fp32 operations in the same order per element as level1_filter, so
+// verdicts, rechecks and minima are identical to the one-position form (option l1_exp bit 1 selects that form).
+typedef float rows_f2 __attribute__((ext_vector_type(2)));
+typedef int rows_i2u __attribute__((ext_vector_type(2), aligned(4)));
+typedef float rows_f2u __attribute__((ext_vector_type(2), aligned(4)));
+
+struct RowsStep2
+{
+    unsigned ia, ib;  // slots of (X, a) and of (X, b)
+    int a, b, X, first_lane;
+    bool in0, in1;  // position b / b + 1 is a real position of this wave's range
+    rows_i2u nb;    // list entries at b, b + 1 (the second one is only meaningful when in1)
+    rows_f2u rbu;
+    int yb0, yb1;
+    float ra;
+    rows_f2 c;
+};
+
+template <int MODE, bool VALIDATE>
+__global__ void __launch_bounds__(kRowsThreads) level1_rows2_kernel(SweepParams p, RowsParams rp)
+{
+    __shared__ int4 s_seg[kRowsChunk];  // {slot of (X, a), a, C[X, row] bits, X}
+    __shared__ int s_dx[kRowsChunk];    // degree of X
+    __shared__ int s_pre[kRowsChunk + 1];
+    __shared__ int s_wtot[2][kRowsThreads / 64];
+    __shared__ unsigned long long s_cnt[4];
+    const int n = p.n;
+    const int ya = blockIdx.x;
+    if (!p.cnt->active) return;
+    const int o0 = p.off[ya];
+    const int d = p.off[ya + 1] - o0;
+    if (d == 0 || ya + 1 >= n) return;
+    if (rp.shard_world > 1 && ya % rp.shard_world != rp.shard_rank) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int kWaves = kRowsThreads >> 6;
+    if (tid < 4) s_cnt[tid] = 0ull;
+    int4 m = make_int4(0, 0, 0, 0);
+    float mra = 0.0f;
+    if (tid < d)
+    {
+        m = rp.meta[o0 + tid];
+        mra = rp.rv[m.z + m.y];  // C[X, row]
+    }
+    const float *crow = p.C + (size_t)ya * n;
+    [[maybe_unused]] int tiA = 0;
+    if constexpr (MODE == 1) tiA = p.time_index[ya];
+    const bool use_filter = rp.use_filter != 0;
+    const float th = p.th, t2 = p.t2, beta = rp.beta;
+    unsigned ntests = 0, nrem = 0, viol = 0;
+    for (int kc = 0; kc < d; kc += kRowsChunk)
+    {
+        // ---- lay the non-empty segments of this round end to end, counted in pairs of positions ----
+        const int len = (kc + tid < d) ? max(0, m.w - m.y - 1) : 0;
+        const int plen = (len + 1) >> 1;
+        int pos = (plen > 0) ? 1 : 0, pre = plen;
+        for (int o = 1; o < 64; o <<= 1)
+        {
+            const int v1 = __shfl_up(pos, o), v2 = __shfl_up(pre, o);
+            if (lane >= o)
+            {
+                pos += v1;
+                pre += v2;
+            }
+        }
+        if (kc > 0) __syncthreads();  // the previous round's readers are done with s_seg / s_pre / s_wtot
+        if (lane == 63)
+        {
+            s_wtot[0][wave] = pos;
+            s_wtot[1][wave] = pre;
+        }
+        __syncthreads();
+        int nseg = 0, total = 0, pos0 = 0, pre0 = 0;
+#pragma unroll
+        for (int w = 0; w < kWaves; w++)
+        {
+            const int c1 = s_wtot[0][w], c2 = s_wtot[1][w];
+            if (w < wave)
+            {
+                pos0 += c1;
+                pre0 += c2;
+            }
+            nseg += c1;
+            total += c2;
+        }
+        if (plen > 0)
+        {
+            s_seg[pos0 + pos - 1] = make_int4(m.z + m.y, m.y, __float_as_int(mra), m.x);
+            s_dx[pos0 + pos - 1] = m.w;
+            s_pre[pos0 + pos - 1] = pre0 + pre - plen;
+        }
+        if (tid == 0) s_pre[nseg] = total;
+        if (kc + kRowsChunk + tid < d)
+        {  // next round, in flight meanwhile
+            m = rp.meta[o0 + kc + kRowsChunk + tid];
+            mra = rp.rv[m.z + m.y];
+        }
+        __syncthreads();
+        // ---- this wave's contiguous share of the flat range ----
+        const int per = ((total + kWaves * 64 - 1) / (kWaves * 64)) * 64;
+        const int f_begin = wave * per, f_end = min(total, f_begin + per);
+        if (f_begin >= f_end) continue;
+        int kw = 0;
+        {
+            int hi = nseg;  // largest kw with s_pre[kw] <= f_begin
+            while (hi - kw > 1)
+            {
+                const int mid = (kw + hi) >> 1;
+                if (s_pre[mid] <= f_begin)
+                    kw = mid;
+                else
+                    hi = mid;
+            }
+        }
+        // stage A: locate the lanes of a step inside the segments and request the per-slot operands.  Lanes past the
+        // end of the wave's range idle on slot a of the last segment (their "neighbour" is the row itself), so every
+        // request is unconditional.
+        auto stage_a = [&](int base, RowsStep2 &st) {
+            const int f = base + lane;
+            st.in0 = f < f_end;
+            int kk = kw;
+            if (st.in0)
+                while (s_pre[kk + 1] <= f) kk++;
+            kw = __shfl(kk, 63);
+            const int seg0 = s_pre[kk];
+            const int4 e = s_seg[kk];
+            const int dX = s_dx[kk];
+            const int r = st.in0 ? 2 * (f - seg0) + 1 : 0;
+            st.a = e.y;
+            st.b = e.y + r;
+            st.in1 = st.in0 && (st.b + 1 < dX);
+            st.ra = __int_as_float(e.z);
+            st.X = e.w;
+            st.first_lane = max(0, seg0 - base);
+            st.ia = (unsigned)e.x;
+            st.ib = (unsigned)(e.x + r);
+            st.nb = *reinterpret_cast<const rows_i2u *>(reinterpret_cast<const char *>(p.nbr) + (st.ib << 2));
+            st.rbu = *reinterpret_cast<const rows_f2u *>(reinterpret_cast<const char *>(rp.rv) + (st.ib << 2));
+        };
+        auto stage_b = [&](RowsStep2 &st) {
+            st.yb0 = st.nb.x;
+            st.yb1 = st.in1 ? st.nb.y : st.nb.x;  // the entry behind an odd segment belongs to another list
+            st.c.x = ld32<float>(crow, (unsigned)st.yb0);
+            st.c.y = ld32<float>(crow, (unsigned)st.yb1);
+        };
+        auto stage_c = [&](const RowsStep2 &cur) {
+            const int a = cur.a, b = cur.b;
+            const float ra = cur.ra;
+            const rows_f2 c = cur.c;
+            const rows_f2 rb = {cur.rbu.x, cur.rbu.y};
+            bool needA0, needB0, needA1, needB1;  // A: Y = ya, S = yb ; B: Y = yb, S = ya
+            if constexpr (MODE == 0)
+            {
+                needA0 = needB0 = cur.in0;
+                needA1 = needB1 = cur.in1;
+            }
+            else
+            {
+                const int tiX = p.time_index[cur.X], tiB0 = p.time_index[cur.yb0], tiB1 = p.time_index[cur.yb1];
+                needA0 = cur.in0 && !(tiB0 > max(tiX, tiA));
+                needB0 = cur.in0 && !(tiA > max(tiX, tiB0));
+                needA1 = cur.in1 && !(tiB1 > max(tiX, tiA));
+                needB1 = cur.in1 && !(tiA > max(tiX, tiB1));
+            }
+            // per element exactly the operations of the one-position form: 1 - (c c), ra - (rb c), t2 ((h00) (hc)), ...
+            const rows_f2 one = {1.0f, 1.0f}, rav = {ra, ra};
+            const rows_f2 hc = one - (c * c);
+            const rows_f2 h00a = one - (rb * rb), h01a = rav - (rb * c);
+            const float h00b = 1.0f - (ra * ra);
+            const rows_f2 h00bv = {h00b, h00b}, h01b = rb - (rav * c);
+            const rows_f2 lhsA = h01a * h01a, rhsA = t2 * (h00a * hc);
+            const rows_f2 lhsB = h01b * h01b, rhsB = t2 * (h00bv * hc);
+            const rows_f2 loA = rhsA * (1.0f - beta), hiA = rhsA * (1.0f + beta);
+            const rows_f2 loB = rhsB * (1.0f - beta), hiB = rhsB * (1.0f + beta);
+            const bool ok0 = use_filter && (hc.x > 0.0f), ok1 = use_filter && (hc.y > 0.0f), okb = h00b > 0.0f;
+            bool passA0 = lhsA.x < loA.x, passA1 = lhsA.y < loA.y, passB0 = lhsB.x < loB.x, passB1 = lhsB.y < loB.y;
+            const bool sureA0 = ok0 && (h00a.x > 0.0f) && (passA0 || lhsA.x > hiA.x);
+            const bool sureA1 = ok1 && (h00a.y > 0.0f) && (passA1 || lhsA.y > hiA.y);
+            const bool sureB0 = ok0 && okb && (passB0 || lhsB.x > hiB.x);
+            const bool sureB1 = ok1 && okb && (passB1 || lhsB.y > hiB.y);
+            ntests += (needA0 ? 1u : 0u) + (needB0 ? 1u : 0u) + (needA1 ? 1u : 0u) + (needB1 ? 1u : 0u);
+            const bool slowA0 = needA0 && (VALIDATE || !sureA0), slowB0 = needB0 && (VALIDATE || !sureB0);
+            const bool slowA1 = needA1 && (VALIDATE || !sureA1), slowB1 = needB1 && (VALIDATE || !sureB1);
+            if (__ballot(slowA0 || slowB0 || slowA1 || slowB1) != 0ull)
+            {  // rare: the reference's operation order
+                if (slowA0)
+                {
+                    const bool ex = level1_exact(h00a.x, h01a.x, hc.x, th);
+                    if (VALIDATE && sureA0 && ex != passA0) viol++;
+                    passA0 = ex;
+                }
+                if (slowB0)
+                {
+                    const bool ex = level1_exact(h00b, h01b.x, hc.x, th);
+                    if (VALIDATE && sureB0 && ex != passB0) viol++;
+                    passB0 = ex;
+                }
+                if (slowA1)
+                {
+                    const bool ex = level1_exact(h00a.y, h01a.y, hc.y, th);
+                    if (VALIDATE && sureA1 && ex != passA1) viol++;
+                    passA1 = ex;
+                }
+                if (slowB1)
+                {
+                    const bool ex = level1_exact(h00b, h01b.y, hc.y, th);
+                    if (VALIDATE && sureB1 && ex != passB1) viol++;
+                    passB1 = ex;
+                }
+            }
+            passA0 = passA0 && needA0;
+            passB0 = passB0 && needB0;
+            passA1 = passA1 && needA1;
+            passB1 = passB1 && needB1;
+            // Y = ya: positions ascend with the lane inside a segment (and b before b + 1 inside a lane), so the lowest
+            // passing lane of a segment carries the segment's minimum; only that lane speaks
+            const bool anyA = passA0 || passA1;
+            const unsigned long long pa = __ballot(anyA);
+            const unsigned long long below = pa & ((1ull << lane) - 1ull) & ~((1ull << cur.first_lane) - 1ull);
+            const bool headA = anyA && (below == 0ull);
+            const int bsel = passA0 ? b : b + 1;
+            if (rp.exp & 4) nrem += (passB0 ? 1u : 0u) + (passB1 ? 1u : 0u) + (headA ? 1u : 0u);
+            if constexpr (MODE == 0)
+            {
+                // fire-and-forget minima: nobody waits for the L2 round trip; which slots got a separating set is
+                // counted once afterwards
+                if (passB0) (void)__hip_atomic_fetch_min(&rp.sel[cur.ib], (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (passB1) (void)__hip_atomic_fetch_min(&rp.sel[cur.ib + 1], (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (headA) (void)__hip_atomic_fetch_min(&rp.sel[cur.ia], (unsigned)bsel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            else
+            {
+                // hetcor: the edge goes in both directions; both directed slots are marked with plain stores (racing
+                // writers store the same 0), bitmap and degrees are updated once afterwards (level1_apply_kernel)
+                if (passB0)
+                {
+                    rp.sel[cur.ib] = 0u;
+                    rp.sel[p.off[cur.yb0] + rp.meta[cur.ib].y] = 0u;
+                }
+                if (passB1)
+                {
+                    rp.sel[cur.ib + 1] = 0u;
+                    rp.sel[p.off[cur.yb1] + rp.meta[cur.ib + 1].y] = 0u;
+                }
+                if (headA)
+                {
+                    rp.sel[cur.ia] = 0u;
+                    rp.sel[o0 + rp.meta[cur.ia].y] = 0u;
+                }
+            }
+        };
+        // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
+        // the set it needs); the scheduling barriers keep the requests ahead of the evaluation
+        RowsStep2 s0, s1, s2;
+        stage_a(f_begin, s0);
+        stage_a(f_begin + 64, s1);
+        stage_b(s0);
+        for (int base = f_begin;; base += 192)
+        {
+            stage_a(base + 128, s2);
+            stage_b(s1);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s0);
+            if (base + 64 >= f_end) break;
+            stage_a(base + 192, s0);
+            stage_b(s2);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s1);
+            if (base + 128 >= f_end) break;
+            stage_a(base + 256, s1);
+            stage_b(s0);
+            __builtin_amdgcn_sched_barrier(0);
+            stage_c(s2);
+            if (base + 192 >= f_end) break;
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1)
+    {
+        ntests += __shfl_xor(ntests, o);  // < 2^32 per wave
         nrem += __shfl_xor(nrem, o);
         if (VALIDATE) viol += __shfl_xor(viol, o);
     }
@@ -1206,20 +1526,42 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.meta = static_cast<const int4 *>(meta);
     rp.sel = sel;
     rp.use_filter = use_filter ? 1 : 0;
+    rp.beta = (exp & 512) ? kBeta : level1_beta(p.t2);  // bit 512: the wide band of the deeper levels
     rp.exp = exp;
     rp.shard_rank = shard_rank;
     rp.shard_world = shard_world;
     const dim3 grid((unsigned)((exp & 2) ? ((n + 7) / 8) * 8 : n));
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
+    const bool two = !(exp & 1) && !(exp & 2);  // two list positions per lane (default); bit 1: the one-position form
     if (mode == 0 && !validate)
-        hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, 0, st, p, rp);
+    {
+        if (two)
+            hipLaunchKernelGGL((level1_rows2_kernel<0, false>), grid, blk, 0, st, p, rp);
+        else
+            hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, 0, st, p, rp);
+    }
     else if (mode == 0)
-        hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, 0, st, p, rp);
+    {
+        if (two)
+            hipLaunchKernelGGL((level1_rows2_kernel<0, true>), grid, blk, 0, st, p, rp);
+        else
+            hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, 0, st, p, rp);
+    }
     else if (!validate)
-        hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, 0, st, p, rp);
+    {
+        if (two)
+            hipLaunchKernelGGL((level1_rows2_kernel<1, false>), grid, blk, 0, st, p, rp);
+        else
+            hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, 0, st, p, rp);
+    }
     else
-        hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
+    {
+        if (two)
+            hipLaunchKernelGGL((level1_rows2_kernel<1, true>), grid, blk, 0, st, p, rp);
+        else
+            hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
+    }
     if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode != 0 && !defer_apply)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,

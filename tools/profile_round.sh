@@ -35,7 +35,7 @@ def per_launch(kpat):
     f = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "FETCH_SIZE"]
     w = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "WRITE_SIZE"]
     return (f[0] if f else 0.0) * 1024, (w[0] if w else 0.0) * 1024
-f1, w1 = per_launch("level1_rows_kernel")
+f1, w1 = per_launch("level1_rows")
 # calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"): the level-0 kernel
 # streams the upper triangle of the 10020^2 fp32 matrix once with the same 4-byte-per-lane coalesced loads
 f0, _ = per_launch("level0_wide_kernel")
