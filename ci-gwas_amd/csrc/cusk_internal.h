@@ -16,10 +16,12 @@ constexpr int kLevels = CUSK_ML + 2;  // per-level device records, index = level
 constexpr unsigned long long kNone = ~0ull;
 // degree classes of the level sweep: rows whose (d+1)^2 sub-matrix fits the class
 // capacity are staged in LDS; the last class reads C from global memory.
-// (one class up to 63 neighbours: rows of that size are VGPR-limited, not LDS-limited, so a finer split only added a
-// launch and a stream fork per level)
-constexpr int kNumClasses = 4;
-constexpr int kClassCap[kNumClasses] = {63, 127, 191, 1 << 30};
+// The first class (up to 39 neighbours: every row of an LD block from level 2 on) is swept with ONE WAVEFRONT per work
+// item (sweep_vec.hip) and a smaller work item: its sub-matrix takes 8 KB of LDS, so a CU holds 16-20 items at once
+// instead of 4-8 and the per-item chain of dependent loads (item -> offsets -> list -> operands) is hidden by other
+// items rather than paid serially.
+constexpr int kNumClasses = 5;
+constexpr int kClassCap[kNumClasses] = {39, 63, 127, 191, 1 << 30};
 constexpr int kThreads = 256;
 constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many slots
 constexpr size_t kLdsLimit = 160 * 1024;
@@ -75,6 +77,8 @@ struct cusk_engine
     cusk::DevBuf deg, binom, counters, slots, rec_base, ti, queue, symflag;
     // per-level working sets, ping-pong by level parity
     cusk::DevBuf off[2], nbr[2], best[2];
+    cusk::DevBuf planblk;  // published block totals of the plan kernel
+    unsigned plan_seq = 0;
     cusk::DevBuf off1;  // CSR offsets of level 1 (kept for the whole run: records live at level-1 slots)
     cusk::DevBuf items[2][cusk::kNumClasses];
     // sparse record store, indexed by level-1 CSR slot (rec_l = 0: empty); rec_s is member-major with stride rec_cap
@@ -118,7 +122,10 @@ struct cusk_engine
     int opt_corr_popcount = 0;
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
+    int opt_hostprof = 0;
     long long opt_chunk = 2048;
+    long long opt_chunk0 = 512;   // conditioning sets per work item of the first degree class
+    int opt_vec_threads = 64;     // workgroup size of sweep_vec_kernel for the first degree class (64 / 128 / 256)
     long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
     int opt_lookahead = 2;
     int opt_l1_exp = 0;                  // level-1 row kernel experiment bits (sweep_level.hip: RowsParams::exp)

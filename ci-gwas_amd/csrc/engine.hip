@@ -14,6 +14,7 @@
 // whose recheck queue overflowed can be redone on the exact path after the fact.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 
@@ -89,12 +90,23 @@ struct LevelPlan
     bool known_items = false;  // nitems[] holds the level's real class counts (row-sharded runs wait for them)
     int maxdeg_bound = 0;      // no row has more neighbours than this (newest maximum degree the host has seen)
     int staged_classes = 0;
+    unsigned long long chunk0 = 0;  // conditioning sets per work item of the first degree class at this level
 };
 
 static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
 {
     const int n = a.n;
     if (n <= 0 || a.C == nullptr || a.Th == nullptr) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    // option hostprof: host-side phase marks of the run (microseconds since entry) on stderr
+    const auto hp_t0 = std::chrono::steady_clock::now();
+    std::string hp_log;
+    auto hp_mark = [&](const char *what) {
+        if (!e->opt_hostprof) return;
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - hp_t0).count();
+        char buf[64];
+        std::snprintf(buf, sizeof(buf), " %s=%.1f", what, us);
+        hp_log += buf;
+    };
     CUSK_HIP(e, hipSetDevice(e->device));
     hipStream_t s = e->stream;
     const int words = (n + 63) / 64;
@@ -127,6 +139,16 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         for (int c = 0; c < kNumClasses; c++) CUSK_HIP(e, e->items[k][c].ensure(sizeof(int2) * (size_t)item_cap));
     }
     CUSK_HIP(e, e->off1.ensure(sizeof(int) * ((size_t)n + 1)));
+    {  // plan kernel: 8 words per 256-row block, validated by a 24-bit launch sequence number (cleared when it wraps or the buffer is new)
+        const size_t need = sizeof(unsigned long long) * 8 * (((size_t)n + 255) / 256);
+        const bool fresh = need > e->planblk.cap;
+        CUSK_HIP(e, e->planblk.ensure(need));
+        if (fresh || e->plan_seq >= 0xfffff0u)
+        {
+            CUSK_HIP(e, hipMemsetAsync(e->planblk.p, 0, e->planblk.cap, s));
+            e->plan_seq = 0;
+        }
+    }
     const int run_seq = ++e->run_seq;
     e->records_ready = e->z_ready = false;
     e->rec_slots = 0;
@@ -158,6 +180,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
     }
     CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
+    hp_mark("l0_enq");
     local.max_degree[0] = n - 1;
     local.edges[0] = (long long)n * (n - 1);
     local.tests[0] = (long long)n * (n - 1) / 2;
@@ -175,6 +198,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     unsigned long long qcap_gate[kLevels];
     for (auto &q : qcap_gate) q = ~0ull;
 
+    const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
+    const unsigned long long chunk0 = (unsigned long long)std::max<long long>(e->opt_chunk0, 64);
     auto launch_level_sweeps = [&](int l, bool exact_only) -> int {
         LevelPlan &pl = plan[l];
         SweepParams sp = pl.sp;
@@ -219,12 +244,13 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.items = e->items[l & 1][c].as<int2>();
             sp.cap = kClassCap[c];
             sp.cls = c;
+            sp.chunk = (c == 0) ? pl.chunk0 : chunk;
             sp.item_cap = item_cap;
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.pair_lds, cs));
             else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
                      sweep_vec_lds_bytes(c) <= kLdsLimit && l < kVecMaxLevel)
-                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, cs));
+                CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, c == 0 ? e->opt_vec_threads : kThreads, cs));
             else if (pl.use_fast && !exact_only)
                 CUSK_HIP(e, launch_sweep_fast(a.mode, het, l, e->opt_validate != 0, sp, c, cs));
             else
@@ -305,7 +331,6 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // which classes can be staged in LDS in this mode
     int staged_classes = 0;
     while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit) staged_classes++;
-    const unsigned long long chunk = (unsigned long long)std::max<long long>(e->opt_chunk, 256);
     // The host enqueues levels AHEAD of the device: every kernel of a level checks the level's gate on the device
     // (LevelCounters::active, set by the level's plan), sweeps are persistent launches that read their work-item counts
     // on the device, so no launch needs a number from the host.  The host only follows `lookahead` levels behind (it
@@ -349,7 +374,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (rc != CUSK_OK) return rc;
             rc = launch_level_finalize(redo);
             if (rc != CUSK_OK) return rc;
-            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
+            if (e->opt_timing == 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[redo], s));
             redo = 0;
         }
         int enq_last = start - 1;
@@ -365,7 +390,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     if (!e->hgate[k].active) break;
                 }
             }
-            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
+            if (e->opt_timing == 2) CUSK_HIP(e, hipEventRecord(e->ev_l0[l], s));
             LevelPlan &pl = plan[l];
             pl.redone = false;
             pl.known_items = false;
@@ -382,6 +407,21 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             pa.L = l;
             pa.binom = e->binom.as<unsigned long long>();
             pa.chunk = chunk;
+            // the small work item only where the one-wavefront kernel runs (sweep_vec.hip); the 256-thread kernels of the
+            // same class (exact path, heterogeneous thresholds, levels >= kVecMaxLevel) want long runs of consecutive ranks
+            {
+                float th_l;
+                if (a.mode == 0)
+                    th_l = a.Th[l];
+                else if (het)
+                    th_l = a.Th[0];
+                else
+                    th_l = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
+                const bool vec0 = (e->opt_fast != 0) && l >= 2 && l < kVecMaxLevel && th_l >= kThMinFilter && !het && e->opt_vec &&
+                                  !e->opt_validate && staged_classes > 0;
+                plan[l].chunk0 = vec0 ? chunk0 : chunk;
+            }
+            pa.chunk0 = plan[l].chunk0;
             pa.staged_classes = staged_classes;
             pa.pair_mode = ((l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows) ? 1 : 0;
             pa.cnt = dcnt + l;
@@ -393,6 +433,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             pa.gate = e->hgate_dev + l;
             pa.seq = run_seq;
             pa.sym = (l == 1 && !e->opt_assume_symmetric) ? dsym : nullptr;
+            pa.blocks = e->planblk.as<unsigned long long>();
+            pa.blk_seq = ++e->plan_seq;
             if (first_build && e->binom_rows <= 0)
             {  // the plan reads C(d, 1) = d only at level 1, but wants a valid table pointer
                 CUSK_HIP(e, e->binom.ensure(sizeof(unsigned long long) * kBinomStride));
@@ -403,8 +445,10 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             {
                 // the run's one mandatory round trip: sizes of the CSR arrays and of the binomial table come from the
                 // level-1 degrees
+                hp_mark("plan1_enq");
                 int rc = wait_gate(1);
                 if (rc != CUSK_OK) return rc;
+                hp_mark("gate1");
                 symmetric = (e->hgate[1].sym == 0) || (e->opt_assume_symmetric != 0);
                 cap_edges = std::max<long long>(e->hgate[1].total_edges, 1);
                 maxdeg1 = e->hgate[1].maxdeg;
@@ -454,6 +498,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     pa.binom = e->binom.as<unsigned long long>();
                     pa.seq = run_seq;
                     e->hgate[1].seq = 0;
+                    pa.blk_seq = ++e->plan_seq;
                     CUSK_HIP(e, launch_plan(pa, s));
                 }
                 first_pass = false;
@@ -548,10 +593,10 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             fp.slots = sp.slots;
             fp.canon = dcanon + (size_t)l * kCounterSlots;
 
-            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
+            if (e->opt_timing == 1 || e->opt_timing == 2) CUSK_HIP(e, hipEventRecord(e->ev_k0[l], s));
             int rc = launch_level_sweeps(l, false);
             if (rc != CUSK_OK) return rc;
-            if (e->opt_timing) CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
+            if (e->opt_timing == 1 || e->opt_timing == 2) CUSK_HIP(e, hipEventRecord(e->ev_k1[l], s));
             if (sharded)
             {
                 rc = shard_join(l);
@@ -559,7 +604,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             }
             rc = launch_level_finalize(l);
             if (rc != CUSK_OK) return rc;
-            if (e->opt_timing >= 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
+            if (e->opt_timing == 2) CUSK_HIP(e, hipEventRecord(e->ev_l1[l], s));
             enq_last = l;
         }
 
@@ -569,7 +614,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         // counters, slots and record bases in one copy (hcnt, hslots, hrec_base point into the pinned mirror)
         CUSK_HIP(e, hipMemcpyAsync(e->hcnt, ctl, ctl_sym, hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipEventRecord(e->ev_run[1], s));
+        hp_mark("all_enq");
         CUSK_HIP(e, hipStreamSynchronize(s));
+        hp_mark("synced");
         int ended = 0;  // first level whose gate stayed closed
         for (int l = 1; l <= enq_last && !ended; l++)
             if (!e->hcnt[l].active) ended = l;
@@ -621,7 +668,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     float ms = 0.0f;
     CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[0], e->ev_l1[0]));
     local.kernel_ms[0] = local.level_ms[0] = ms;
-    const bool timed = e->opt_timing != 0;
+    const bool timed = (e->opt_timing == 1 || e->opt_timing == 2);
     for (int l = 1; l <= levels_swept; l++)
     {
         for (int k = 0; k < kCounterSlots; k++)
@@ -634,7 +681,15 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             if (a.mode == 0) local.canonical_tests[l] += (long long)e->hcanon[(size_t)l * kCounterSlots + k];
         }
         local.rechecks[l] = (long long)e->hcnt[l].qcount;
-        if (!timed) continue;
+        if (!timed)
+        {  // timing = 3: the events around the level-1 row kernel only
+            if (e->opt_timing == 3 && l == 1 && rows_timed)
+            {
+                CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_main[0], e->ev_main[1]));
+                local.main_kernel_ms[l] = ms;
+            }
+            continue;
+        }
         CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_k0[l], e->ev_k1[l]));
         local.kernel_ms[l] = ms;
         local.main_kernel_ms[l] = ms;
@@ -645,7 +700,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         }
         // level time: plan to finaliser with timing = 2; otherwise from the end of the previous level's sweep to the
         // end of this one's (the previous finaliser, this level's plan, lists and sweep)
-        if (e->opt_timing >= 2)
+        if (e->opt_timing == 2)
             CUSK_HIP(e, hipEventElapsedTime(&ms, e->ev_l0[l], e->ev_l1[l]));
         else
             CUSK_HIP(e, hipEventElapsedTime(&ms, l == 1 ? e->ev_l1[0] : e->ev_k1[l - 1], e->ev_k1[l]));
@@ -658,6 +713,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     e->nrec = 0;  // the dense record list is produced on request (materialize_records)
     e->have_result = true;
     if (st) *st = local;
+    hp_mark("done");
+    if (e->opt_hostprof) std::fprintf(stderr, "[hostprof]%s\n", hp_log.c_str());
     return CUSK_OK;
 }
 
@@ -742,7 +799,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
                       &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_s, &e->den_x, &e->den_y, &e->den_l,
-                      &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->scratch_a, &e->scratch_b, &e->bed_dev, &e->phen_dev,
+                      &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->planblk, &e->scratch_a, &e->scratch_b, &e->bed_dev, &e->phen_dev,
                       &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
         b->release();
     for (int k = 0; k < 2; k++)
@@ -797,6 +854,12 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)
         e->opt_chunk = value;
+    else if (k == "hostprof")
+        e->opt_hostprof = (int)value;
+    else if (k == "chunk0" && value >= 64)
+        e->opt_chunk0 = value;
+    else if (k == "vec_threads" && (value == 64 || value == 128 || value == 256))
+        e->opt_vec_threads = (int)value;
     else if (k == "item_capacity" && value > 0)
     {
         e->opt_item_cap = value;

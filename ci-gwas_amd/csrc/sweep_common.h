@@ -240,7 +240,7 @@ hipError_t launch_rec_compact(const int *rec_l, const int *rec_x, const int *rec
 // sweep_fast.hip
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st);
 // sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
-hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, hipStream_t st);
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, int threads, hipStream_t st);
 // workgroups of a persistent sweep launch: what the chip holds at once for this kernel (occupancy x CUs), cached
 unsigned persistent_grid(const void *kernel, int threads, size_t lds);
 size_t sweep_vec_lds_bytes(int cls);
@@ -261,7 +261,7 @@ struct PlanArgs
     int2 *items[kNumClasses];
     int n, L;
     const unsigned long long *binom;
-    unsigned long long chunk;
+    unsigned long long chunk, chunk0;  // conditioning sets per work item: classes >= 1, class 0
     int staged_classes, pair_mode;
     LevelCounters *cnt;
     const LevelCounters *prev;
@@ -271,6 +271,8 @@ struct PlanArgs
     HostGate *gate;
     int seq;
     const int *sym;
+    unsigned long long *blocks;  // ceil(n / 256) x 8 published block totals (plan_kernel)
+    unsigned blk_seq;            // 24-bit sequence number of this launch, never 0, different from every launch that wrote `blocks` before
 };
 hipError_t launch_plan(const PlanArgs &a, hipStream_t st);
 hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long rec_cap, long long count, int *out,

@@ -392,14 +392,29 @@ __device__ __forceinline__ long long prefix_256(const int *__restrict__ in, int 
 }
 
 // The level's work plan, from the degrees alone (so it runs before the neighbour lists are even written): CSR offsets,
-// class and work-item count of every row, the work items themselves (placed inside the class buffers by block scans +
-// one atomicAdd per class and workgroup; order between workgroups is irrelevant: items of a class are independent),
-// level totals, and the level's gate.  256 rows per workgroup.
+// class and work-item count of every row, the work items themselves, level totals, and the level's gate.  256 rows per
+// workgroup.
+//
+// Round 2, second form: no same-address atomics.  The first form placed a workgroup's items with one returning atomicAdd
+// per class, took the maximum degree with an atomicMax and found the last workgroup with a ticket counter: three to seven
+// device-scope atomics on the same few addresses from every workgroup, which serialise at ~0.3-0.5 us each across the
+// XCDs -- 18-23 us per level for a kernel that moves 40 KB.  Now every workgroup PUBLISHES its block totals (degree sum,
+// items per class, maximum degree) as self-validating 64-bit words, (sequence number << 40) | value, written with
+// agent-scope stores, and reads the words of the blocks before it (spinning on a word until it carries this launch's
+// sequence number: no fence, no flag).  Exclusive sums over the earlier blocks give the CSR offsets and the placement
+// of the items -- in row order, so the item lists are deterministic -- and the LAST block, which has seen every other
+// block's totals, closes or opens the gate.  Forward progress: a workgroup only waits for workgroups with a smaller
+// index, which the dispatcher starts first and which never wait for a larger one.
+constexpr int kPlanWords = 8;  // per block: [0] degree sum, [1 .. kNumClasses] items per class, [6] maximum degree, [7] overflow
+static_assert(kNumClasses + 1 < 7, "plan words");
+constexpr unsigned long long kPlanMask = (1ull << 40) - 1ull;
+
 __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
 {
     __shared__ int s_wave[kNumClasses][4];
+    __shared__ int s_wdeg[4], s_wmax[4];
+    __shared__ long long s_part[4][kPlanWords];
     __shared__ long long s_base[kNumClasses];
-    __shared__ long long s_red[8];
     __shared__ int s_cls[256], s_nch[256], s_pos[256];
     __shared__ unsigned long long s_big[4];
     LevelCounters *cnt = a.cnt;
@@ -424,51 +439,39 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
         }
         return;
     }
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tid = threadIdx.x;
+    const int row = blockIdx.x * 256 + tid;
+    const int lane = tid & 63, wave = tid >> 6;
     int cls = -1, nchunks = 0;
     const int d = (row < n) ? a.deg[row] : 0;
+    bool ovf = false;
     if (d > L)
     {
         // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
         const unsigned long long nc = a.pair_mode ? (unsigned long long)d * (d - 1) / 2
                                                   : (L == 1 ? (unsigned long long)d : a.binom[(size_t)d * kBinomStride + L]);
         if (nc >= (1ull << 62))
-            atomicOr(&cnt->overflow, 1);
+            ovf = true;
         else if (a.shard_world == 1 || row % a.shard_world == a.shard_rank)
         {  // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow check are global)
             cls = 0;
             while (d > kClassCap[cls]) cls++;
             if (cls >= a.staged_classes) cls = kNumClasses - 1;
-            nchunks = (int)((nc + a.chunk - 1) / a.chunk);
+            const unsigned long long ch = (cls == 0) ? a.chunk0 : a.chunk;
+            nchunks = (int)((nc + ch - 1) / ch);
         }
     }
-    // CSR offsets of the level (exclusive prefix of the degrees); the last workgroup knows the edge total
+    const bool wave_ovf = __ballot(ovf) != 0ull;
+    // ---- scans inside the workgroup: degrees, items per class, maximum degree ----
+    int dincl = d, dmax = d;
+    for (int o = 1; o < 64; o <<= 1)
     {
-        long long block_total;
-        const long long o0 = prefix_256(a.deg, n, d, s_red, &block_total);
-        if (row < n) a.off[row] = (int)o0;
-        if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0)
-        {
-            const long long total = s_red[4] + s_red[5] + s_red[6] + s_red[7] + block_total;
-            a.off[n] = (int)total;
-            __hip_atomic_store(&cnt->total_edges, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        const int t = __shfl_up(dincl, o);
+        if (lane >= o) dincl += t;
     }
-    // maximum degree: reduced over the workgroup first, one atomic per workgroup (same-address atomics from
-    // different XCDs cost ~0.1-0.3 us each and serialise)
-    {
-        int dmax = d;
-        for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
-        if (lane == 0) s_wave[0][wave] = dmax;
-        __syncthreads();
-        if (threadIdx.x == 0)
-        {
-            const int m4 = max(max(s_wave[0][0], s_wave[0][1]), max(s_wave[0][2], s_wave[0][3]));
-            if (m4 > 0) atomicMax(&cnt->maxdeg, m4);
-        }
-        __syncthreads();
-    }
+    for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
+    if (lane == 63) s_wdeg[wave] = dincl;
+    if (lane == 0) s_wmax[wave] = dmax | (wave_ovf ? (1 << 30) : 0);  // bit 30: a row's C(d, l) does not fit 62 bits
     int excl[kNumClasses];
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
@@ -484,13 +487,64 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
         if (lane == 63) s_wave[c][wave] = v;
     }
     __syncthreads();
-    if (threadIdx.x < kNumClasses)
+    // ---- publish this block's totals ----
+    unsigned long long *blk = a.blocks + (size_t)blockIdx.x * kPlanWords;
+    const unsigned long long tag = (unsigned long long)a.blk_seq << 40;
+    if (tid < kPlanWords)
     {
-        const int c = threadIdx.x;
-        const int tot = s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
-        long long base = tot ? (long long)atomicAdd((unsigned long long *)&cnt->class_items[c], (unsigned long long)tot) : 0;
-        if (base + tot > a.item_cap) base = -1;  // would not fit: the gate stays closed, the host grows the buffers
-        s_base[c] = base;
+        unsigned long long v = 0;
+        if (tid == 0)
+            v = (unsigned long long)((long long)s_wdeg[0] + s_wdeg[1] + s_wdeg[2] + s_wdeg[3]);
+        else if (tid <= kNumClasses)
+            v = (unsigned long long)((long long)s_wave[tid - 1][0] + s_wave[tid - 1][1] + s_wave[tid - 1][2] + s_wave[tid - 1][3]);
+        else if (tid == 6)
+            v = (unsigned long long)(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) & ~(1 << 30));
+        else if (tid == 7)
+            v = (unsigned long long)(((s_wmax[0] | s_wmax[1] | s_wmax[2] | s_wmax[3]) >> 30) & 1);
+        __hip_atomic_store(&blk[tid], tag | (v & kPlanMask), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- totals of the blocks before this one: thread <-> (block j, word w), 32 blocks per round ----
+    long long acc = 0;
+    {
+        const int w = tid & 7;
+        for (int j = tid >> 3; j < (int)blockIdx.x; j += 32)
+        {
+            const unsigned long long *src = a.blocks + (size_t)j * kPlanWords + w;
+            unsigned long long x;
+            while (((x = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) >> 40) != (unsigned long long)a.blk_seq)
+                __builtin_amdgcn_s_sleep(1);
+            const long long v = (long long)(x & kPlanMask);
+            acc = (w >= 6) ? max(acc, v) : acc + v;
+        }
+        for (int o = 8; o < 64; o <<= 1)
+        {
+            const long long t = __shfl_xor(acc, o);
+            acc = (w >= 6) ? max(acc, t) : acc + t;
+        }
+        if (lane < kPlanWords) s_part[wave][lane] = acc;
+    }
+    __syncthreads();
+    long long before[kPlanWords];
+#pragma unroll
+    for (int w = 0; w < kPlanWords; w++)
+    {
+        const long long p0 = s_part[0][w], p1 = s_part[1][w], p2 = s_part[2][w], p3 = s_part[3][w];
+        before[w] = (w >= 6) ? max(max(p0, p1), max(p2, p3)) : p0 + p1 + p2 + p3;
+    }
+    // CSR offsets of the level (exclusive prefix of the degrees)
+    {
+        long long o0 = before[0] + dincl - d;
+        for (int w = 0; w < wave; w++) o0 += s_wdeg[w];
+        if (row < n) a.off[row] = (int)o0;
+    }
+    const bool last = (blockIdx.x == gridDim.x - 1);
+    long long tot_items[kNumClasses];
+#pragma unroll
+    for (int c = 0; c < kNumClasses; c++)
+    {
+        const long long mine = (long long)s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
+        tot_items[c] = before[1 + c] + mine;  // through this block (the last block: the level's total)
+        if (tid == c) s_base[c] = (tot_items[c] > a.item_cap) ? -1 : before[1 + c];  // would not fit: the host grows the buffers
     }
     __syncthreads();
     // the work items of the workgroup's rows, written cooperatively (a hub row has hundreds of them)
@@ -514,9 +568,9 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
         if (lane == 0) s_big[wave] = bm;
         if (big)
         {
-            s_cls[threadIdx.x] = cls;
-            s_nch[threadIdx.x] = nchunks;
-            s_pos[threadIdx.x] = pos;
+            s_cls[tid] = cls;
+            s_nch[tid] = nchunks;
+            s_pos[tid] = pos;
         }
         __syncthreads();
         const int row0 = blockIdx.x * 256;
@@ -529,43 +583,39 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
                 m &= m - 1;
                 const int nch = s_nch[r];
                 int2 *dst = a.items[s_cls[r]] + s_pos[r];
-                for (int c = threadIdx.x; c < nch; c += 256) dst[c] = make_int2(row0 + r, c);
+                for (int c = tid; c < nch; c += 256) dst[c] = make_int2(row0 + r, c);
             }
         }
     }
-    // ---- the level's gate: the last workgroup to arrive sees every total (agent-scope loads: the other workgroups'
-    // atomics were performed at the device's coherence point, not in this XCD's L2) ----
-    __syncthreads();
-    if (threadIdx.x == 0)
+    // ---- the level's totals and gate: the last block has seen every block's words ----
+    if (last && tid == 0)
     {
-        __threadfence();
-        const unsigned ticket = atomicAdd(&cnt->done_blocks, 1u);
-        if (ticket == gridDim.x - 1)
+        const long long edges = before[0] + s_wdeg[0] + s_wdeg[1] + s_wdeg[2] + s_wdeg[3];
+        const int maxdeg = (int)max(before[6], (long long)(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) & ~(1 << 30)));
+        a.off[n] = (int)edges;
+        const int ovf_all = (before[7] != 0 || (((s_wmax[0] | s_wmax[1] | s_wmax[2] | s_wmax[3]) >> 30) & 1)) ? 1 : 0;
+        cnt->overflow = ovf_all;
+        bool fits = true;
+        HostGate *g = a.gate;
+        for (int c = 0; c < kNumClasses; c++)
         {
-            __threadfence();
-            const int maxdeg = __hip_atomic_load(&cnt->maxdeg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int ovf = __hip_atomic_load(&cnt->overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const long long edges = __hip_atomic_load(&cnt->total_edges, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            bool fits = true;
-            HostGate *g = a.gate;
-            for (int c = 0; c < kNumClasses; c++)
-            {
-                const long long ci = __hip_atomic_load(&cnt->class_items[c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                fits = fits && (ci <= a.item_cap);
-                g->class_items[c] = ci;
-            }
-            const int active = (maxdeg - 1 >= L && ovf == 0 && fits) ? 1 : 0;
-            cnt->item_overflow = fits ? 0 : 1;
-            cnt->active = active;
-            g->active = active;
-            g->maxdeg = maxdeg;
-            g->overflow = ovf;
-            g->item_overflow = fits ? 0 : 1;
-            g->sym = a.sym ? *a.sym : 0;
-            g->total_edges = edges;
-            __threadfence_system();
-            *(volatile int *)&g->seq = a.seq;
+            fits = fits && (tot_items[c] <= a.item_cap);
+            cnt->class_items[c] = tot_items[c];
+            g->class_items[c] = tot_items[c];
         }
+        const int active = (maxdeg - 1 >= L && ovf_all == 0 && fits) ? 1 : 0;
+        cnt->maxdeg = maxdeg;
+        cnt->total_edges = edges;
+        cnt->item_overflow = fits ? 0 : 1;
+        cnt->active = active;
+        g->active = active;
+        g->maxdeg = maxdeg;
+        g->overflow = ovf_all;
+        g->item_overflow = fits ? 0 : 1;
+        g->sym = a.sym ? *a.sym : 0;
+        g->total_edges = edges;
+        __threadfence_system();
+        *(volatile int *)&g->seq = a.seq;
     }
 }
 

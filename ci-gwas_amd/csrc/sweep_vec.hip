@@ -34,8 +34,9 @@ __host__ __device__ inline int vec_ld4(int d)
 
 struct VecLayout
 {
-    size_t rel, rowx, nbr, ti, sub, total;
+    size_t rel, rowx, nbr, ti, sub, bin, total;
 };
+constexpr int kVecBinCols = kVecMaxLevel - 2;  // binomial columns C(., 1) .. C(., L - 1) of the unranking, L < kVecMaxLevel
 __host__ __device__ inline VecLayout vec_layout(int cap)
 {
     VecLayout l;
@@ -45,12 +46,43 @@ __host__ __device__ inline VecLayout vec_layout(int cap)
     l.nbr = align16(l.rowx + sizeof(float) * dp);
     l.ti = align16(l.nbr + sizeof(int) * (cap + 1));
     l.sub = align16(l.ti + sizeof(int) * (cap + 1));
-    l.total = align16(l.sub + sizeof(float) * (size_t)(cap + 1) * vec_ld4(cap));
+    l.bin = align16(l.sub + sizeof(float) * (size_t)(cap + 1) * vec_ld4(cap));
+    l.total = align16(l.bin + sizeof(unsigned long long) * (size_t)kVecBinCols * (cap + 1));
     return l;
 }
 
-template <int L, int MODE>
-__global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
+// unrank_comb (sweep_common.h) against the workgroup's LDS copy of the binomial columns: s_bin[(b - 1) * ldb + a] = C(a, b)
+template <int L>
+__device__ __forceinline__ void unrank_comb_lds(unsigned long long rem, int d, const unsigned long long *s_bin, int ldb, int *idx)
+{
+    int c = 0;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        if (i == L - 1)
+        {
+            idx[i] = c + (int)rem;
+            break;
+        }
+        const unsigned long long *col = s_bin + (L - 2 - i) * ldb;  // C(., L - 1 - i)
+        while (true)
+        {
+            const unsigned long long b = col[d - 1 - c];
+            if (rem < b) break;
+            rem -= b;
+            c++;
+        }
+        idx[i] = c;
+        c++;
+    }
+}
+
+// THREADS = 256: a workgroup per work item (rows of 40 and more neighbours).  THREADS = 64: ONE WAVEFRONT per work item,
+// for the first degree class: its LDS carve is ~10 KB, so a CU holds 16 items at once and the chain of dependent loads
+// at the head of every item (offsets -> neighbour list -> operands) overlaps with the arithmetic of the other items;
+// with 256 threads and 4-8 items per CU that chain (~10 us) was most of levels 2 and 3 and a third of levels 4 and 5.
+template <int L, int MODE, int THREADS>
+__global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
 {
     static_assert(L >= 2, "level 1 has its own kernels");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -64,15 +96,25 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     int *s_nbr = reinterpret_cast<int *>(smem + lay.nbr);
     int *s_ti = reinterpret_cast<int *>(smem + lay.ti);
     float *s_sub = reinterpret_cast<float *>(smem + lay.sub);
+    unsigned long long *s_bin = reinterpret_cast<unsigned long long *>(smem + lay.bin);
+    const int ldb = p.cap + 1;
     if (tid < 4) s_cnt[tid] = 0ull;
+    // binomial columns of the unranking, once per workgroup (every row of the class has at most p.cap neighbours)
+    for (int e = tid; e < (L - 1) * ldb; e += THREADS)
+    {
+        const int b = e / ldb, a = e - b * ldb;
+        s_bin[e] = p.binom[(size_t)a * kBinomStride + (b + 1)];
+    }
     unsigned long long ntests = 0, nsub = 0, nrem = 0;
     // persistent launch: the class's work items are counted on the device (sweep_common.h: level_items); a workgroup
     // takes the items blockIdx.x, blockIdx.x + gridDim.x, ... so that the chunks of one row spread over the chip
     const long long nitems = level_items(p);
+    int2 item_next = ((long long)blockIdx.x < nitems) ? p.items[blockIdx.x] : make_int2(0, 0);
     for (long long it = blockIdx.x; it < nitems; it += gridDim.x)
     {
     if (it != (long long)blockIdx.x) __syncthreads();  // the previous item's readers are done with the staged copy
-    const int2 item = p.items[it];
+    const int2 item = item_next;
+    if (it + gridDim.x < nitems) item_next = p.items[it + gridDim.x];  // in flight during this item
     const int X = item.x;
     const int o0 = p.off[X];
     const int d = p.off[X + 1] - o0;
@@ -80,17 +122,17 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     const int dp = (d + 3) & ~3;
     const int *g_nbr = p.nbr + o0;
 
-    const unsigned long long ncomb = p.binom[(size_t)d * kBinomStride + L];
+    const unsigned long long ncomb = p.binom[(size_t)d * kBinomStride + L];  // (uniform: scalar load)
     const unsigned long long r0 = (unsigned long long)item.y * p.chunk;
     const unsigned long long cntr = min(p.chunk, ncomb - r0);
 
-    for (int k = tid; k <= d; k += kThreads)
+    for (int k = tid; k <= d; k += THREADS)
     {
         const int v = (k < d) ? g_nbr[k] : X;
         s_nbr[k] = v;
         if constexpr (MODE == 1) s_ti[k] = p.time_index[v];
     }
-    for (int k = tid; k < dp; k += kThreads)
+    for (int k = tid; k < dp; k += THREADS)
     {
         unsigned rel = 0u;  // padding entries are "decided"
         float rx = 0.0f;
@@ -113,18 +155,43 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
         s_rel[k] = rel;
         s_rowx[k] = rx;
     }
-    __syncthreads();
     {
-        // element (row i, col j) of C[adj(X)]^2 at s_sub[j * ld4 + i]; rows/cols 0..d-1 (X itself is s_rowx)
-        for (int e = tid; e < d * dp; e += kThreads)
+        // element (row i, col j) of C[adj(X)]^2 at s_sub[j * ld4 + i]; rows/cols 0..d-1 (X itself is s_rowx).  The indices
+        // come straight from the global list (cache hits behind the first touch) rather than from the LDS copy above, so
+        // the gathers do not wait for a barrier; kU of them are in flight per lane.
+        constexpr int kU = 8;
+        const int total = d * dp;
+        const int di = THREADS % dp, dj = THREADS / dp;  // one step of THREADS elements in (j, i) coordinates
+        int j = tid / dp, i = tid - j * dp;
+        for (int e0 = tid; e0 < total; e0 += THREADS * kU)
         {
-            const int j = e / dp, i = e - j * dp;
-            s_sub[j * ld4 + i] = (i < d) ? p.C[(size_t)s_nbr[i] * n + s_nbr[j]] : 0.0f;
+            float v[kU];
+            int at[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++)
+            {
+                const bool in = (e0 + u * THREADS < total);
+                at[u] = in ? j * ld4 + i : -1;
+                // unconditional requests (indices clamped into the list): a conditional load would make the compiler
+                // drain every outstanding request at the join
+                const float c = p.C[(size_t)g_nbr[min(i, d - 1)] * n + g_nbr[min(j, d - 1)]];
+                v[u] = (i < d) ? c : 0.0f;
+                i += di;
+                j += dj;
+                if (i >= dp)
+                {
+                    i -= dp;
+                    j++;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++)
+                if (at[u] >= 0) s_sub[at[u]] = v[u];
         }
     }
     __syncthreads();
 
-    const unsigned long long q = (cntr + kThreads - 1) / kThreads;
+    const unsigned long long q = (cntr + THREADS - 1) / THREADS;
     const unsigned long long lo = r0 + (unsigned long long)tid * q;
     const unsigned long long hi = min(r0 + cntr, lo + q);
     const float t2lo = p.t2 * (1.0f - kBeta), t2hi = p.t2 * (1.0f + kBeta);
@@ -133,7 +200,7 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
     if (lo < hi)
     {
         int idx[L];
-        unrank_comb<L>(lo, d, p.binom, idx);
+        unrank_comb_lds<L>(lo, d, s_bin, ldb, idx);
         for (unsigned long long rank = lo; rank < hi; rank++)
         {
             const unsigned myrel = (unsigned)(rank - r0) + 1u;  // >= 1: padding and decided entries (0) are never live
@@ -298,29 +365,37 @@ __global__ void __launch_bounds__(kThreads) sweep_vec_kernel(SweepParams p)
 
 size_t sweep_vec_lds_bytes(int cls) { return vec_layout(kClassCap[cls]).total; }
 
-template <int L, int MODE>
-static hipError_t launch_vec_L(const SweepParams &p, int cls, hipStream_t st)
+template <int L, int MODE, int THREADS>
+static hipError_t launch_vec_LT(const SweepParams &p, int cls, hipStream_t st)
 {
     const size_t lds = vec_layout(kClassCap[cls]).total;
-    auto kfn = sweep_vec_kernel<L, MODE>;
+    auto kfn = sweep_vec_kernel<L, MODE, THREADS>;
     if (lds > 64 * 1024)
     {
         hipError_t e =
             hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
+    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), THREADS, lds),
                                                         std::max<long long>(p.item_cap, 1));
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, st, p);
     return hipGetLastError();
 }
 
-hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, hipStream_t st)
+template <int L, int MODE>
+static hipError_t launch_vec_L(const SweepParams &p, int cls, int threads, hipStream_t st)
+{
+    if (threads == 64) return launch_vec_LT<L, MODE, 64>(p, cls, st);
+    if (threads == 128) return launch_vec_LT<L, MODE, 128>(p, cls, st);
+    return launch_vec_LT<L, MODE, 256>(p, cls, st);
+}
+
+hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, int threads, hipStream_t st)
 {
     switch (L)
     {
 #define CUSK_CASE(LL) \
-    case LL: return mode == 0 ? launch_vec_L<LL, 0>(p, cls, st) : launch_vec_L<LL, 1>(p, cls, st);
+    case LL: return mode == 0 ? launch_vec_L<LL, 0>(p, cls, threads, st) : launch_vec_L<LL, 1>(p, cls, threads, st);
         CUSK_CASE(2)
         CUSK_CASE(3)
         CUSK_CASE(4)
