@@ -186,37 +186,36 @@ __global__ void __launch_bounds__(256) level0_wide_kernel(const float *__restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     s_col[threadIdx.x] = 0ull;
     __syncthreads();
+    // Straight-line fast pass, rare slow pass.  (Round 1 evaluated the in-band elements where they were met: 64 inlined
+    // copies of the Fisher-z comparison made the kernel 90 KB of code, more than the instruction cache holds, and a
+    // conditional request per element; the launch streamed at 2.1 TB/s.)  All 64 requests of a lane are unconditional
+    // (indices clamped into the matrix); the fast pass only compares |c| with the band and remembers which of its
+    // elements fell inside it (about one in a million); those are fetched again and decided by the reference's form
+    // in one rolled loop afterwards.
+    const int i0 = bi * 64 + wave * 16, j0 = bj * kL0Cols + lane;
     float cv[16][4];
 #pragma unroll
     for (int rr = 0; rr < 16; rr++)
     {
-        const int i = bi * 64 + wave * 16 + rr;
+        const size_t ro = (size_t)min(i0 + rr, n - 1) * n;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-        {
-            const int j = bj * kL0Cols + q * 64 + lane;
-            cv[rr][q] = (i < n && j < n && i < j) ? C[(size_t)i * n + j] : 2.0f;  // 2: never removed, never evaluated
-        }
+        for (int q = 0; q < 4; q++) cv[rr][q] = C[ro + min(j0 + q * 64, n - 1)];
     }
     unsigned long long colbits[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned need_lo = 0u, need_hi = 0u;  // bit rr * 4 + q: the element needs the exact comparison
 #pragma unroll
     for (int rr = 0; rr < 16; rr++)
     {
         const int r = wave * 16 + rr;
-        const int i = bi * 64 + r;
+        const int i = i0 + rr;
 #pragma unroll
         for (int q = 0; q < 4; q++)
         {
-            const int j = bj * kL0Cols + q * 64 + lane;
-            const float c = cv[rr][q];
-            const float ac = fabsf(c);
-            bool rm;
-            if (ac < c_lo)
-                rm = true;
-            else if (ac > c_hi && ac <= 1.0f)
-                rm = false;
-            else
-                rm = (i < n && j < n && i < j) && z_below<false>(c, th);
+            const int j = j0 + q * 64;
+            const bool valid = (i < n && j < n && i < j);
+            const float ac = fabsf(cv[rr][q]);
+            const bool rm = valid && (ac < c_lo);
+            const bool need = valid && !(ac < c_lo) && !(ac > c_hi && ac <= 1.0f);  // in the band, |c| > 1, NaN
             const unsigned long long m = __ballot(rm);
             if (lane == 0 && m != 0ull)
             {
@@ -228,13 +227,39 @@ __global__ void __launch_bounds__(256) level0_wide_kernel(const float *__restric
                 unsigned long long *dst = &adj[(size_t)i * words + w];
                 if (complete_graph && w != (i >> 6))
                 {
-                    const int valid = n - w * 64;
-                    *dst = ((valid >= 64) ? ~0ull : ((1ull << valid) - 1ull)) & ~m;
+                    const int nv = n - w * 64;
+                    *dst = ((nv >= 64) ? ~0ull : ((1ull << nv) - 1ull)) & ~m;
                 }
                 else
                     atomicAnd(dst, ~m);
             }
             if (rm) colbits[q] |= (1ull << r);
+            if (need)
+            {
+                if (rr * 4 + q < 32)
+                    need_lo |= 1u << ((rr * 4 + q) & 31);
+                else
+                    need_hi |= 1u << ((rr * 4 + q) & 31);
+            }
+        }
+    }
+    if (__ballot((need_lo | need_hi) != 0u) != 0ull)
+    {
+        // this wave's plain stores above are performed before the read-modify-writes below touch the same words
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        unsigned long long nm = ((unsigned long long)need_hi << 32) | need_lo;
+        while (nm != 0ull)
+        {
+            const int e = __builtin_ctzll(nm);
+            nm &= nm - 1ull;
+            const int rr = e >> 2, q = e & 3;
+            const int i = i0 + rr, j = j0 + q * 64;
+            const float c = C[(size_t)i * n + j];
+            if (z_below<false>(c, th))
+            {
+                atomicAnd(&adj[(size_t)i * words + bj * 4 + q], ~(1ull << lane));  // j % 64 == lane
+                atomicOr(&s_col[q * 64 + lane], 1ull << (wave * 16 + rr));
+            }
         }
     }
 #pragma unroll

@@ -228,6 +228,13 @@ __global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
             for (int a = 0; a < L; a++) col[a] = s_sub + idx[a] * ld4;
             const f2 h00v = {fx.h00, fx.h00};
             bool anyalive = false;
+            // members of S as a bit mask over the list positions (the first degree class has at most 39 of them)
+            [[maybe_unused]] unsigned long long smask = 0ull;
+            if constexpr (THREADS == 64)
+            {
+#pragma unroll
+                for (int a = 0; a < L; a++) smask |= 1ull << idx[a];
+            }
             for (int g = 0; g < dp; g += 4)
             {
                 const u4 rel = *reinterpret_cast<const u4 *>(s_rel + g);
@@ -235,9 +242,14 @@ __global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
                                  (rel.w >= myrel ? 8u : 0u);
                 anyalive |= (livem != 0u);
                 // members of S inside this group of four are not tested
+                if constexpr (THREADS == 64)
+                    livem &= ~((unsigned)(smask >> g) & 15u);
+                else
+                {
 #pragma unroll
-                for (int a = 0; a < L; a++)
-                    if ((idx[a] >> 2) == (g >> 2)) livem &= ~(1u << (idx[a] & 3));
+                    for (int a = 0; a < L; a++)
+                        if ((idx[a] >> 2) == (g >> 2)) livem &= ~(1u << (idx[a] & 3));
+                }
                 if constexpr (MODE == 1)
                 {
 #pragma unroll
@@ -277,6 +289,19 @@ __global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
                 const f2 prodA = h00v * h11A, prodB = h00v * h11B;
                 const f2 lhsA = h01A * h01A, lhsB = h01B * h01B;
                 const f2 loA = prodA * t2lo, loB = prodB * t2lo, hiA = prodA * t2hi, hiB = prodB * t2hi;
+                ntests += __popc(livem);
+                // The common outcome first: every live test of the group certainly fails (edge stays).  One margin per
+                // test, rho^2 side and conditioning side both > 0 (a test exactly on the conditioning bound counts as "not
+                // certain" here and is sorted out by the full masks below, which apply the rule of ci_fast.h literally).
+                unsigned failq;
+                {
+                    const f2 dA = lhsA - hiA, dB = lhsB - hiB;
+                    const f2 eA = h11A - kCondMin, eB = h11B - kCondMin;
+                    // (two comparisons per test, not a min: a NaN on either side must read as "not certain")
+                    failq = ((dA.x > 0.0f && eA.x > 0.0f) ? 1u : 0u) | ((dA.y > 0.0f && eA.y > 0.0f) ? 2u : 0u) |
+                            ((dB.x > 0.0f && eB.x > 0.0f) ? 4u : 0u) | ((dB.y > 0.0f && eB.y > 0.0f) ? 8u : 0u);
+                }
+                if (!fx.ill && (livem & ~failq) == 0u) continue;
                 // verdict masks (bit u = Y index g+u): pass = certainly separated, fail = certainly not
                 unsigned passm = 0u, failm = 0u;
                 passm |= (h11A.x >= kCondMin && lhsA.x < loA.x) ? 1u : 0u;
@@ -292,7 +317,6 @@ __global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
                     passm = 0u;
                     failm = 0u;
                 }
-                ntests += __popc(livem);
                 unsigned todo = livem & ~failm;  // separated or uncertain: leaves the straight line
                 while (todo)
                 {
