@@ -123,6 +123,7 @@ struct cusk_engine
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     int opt_hostprof = 0;
+    int opt_tmaj_min_level = 9;  // first level swept by unions T = S + Y (sweep_tmaj.hip); 99 = never
     long long opt_chunk = 2048;
     long long opt_chunk0 = 512;   // conditioning sets per work item of the first degree class
     int opt_vec_threads = 64;     // workgroup size of sweep_vec_kernel for the first degree class (64 / 128 / 256)

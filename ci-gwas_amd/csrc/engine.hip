@@ -91,6 +91,8 @@ struct LevelPlan
     int maxdeg_bound = 0;      // no row has more neighbours than this (newest maximum degree the host has seen)
     int staged_classes = 0;
     unsigned long long chunk0 = 0;  // conditioning sets per work item of the first degree class at this level
+    bool tmaj = false;         // swept by unions T = S + Y (sweep_tmaj.hip): the work items count (l + 1)-subsets
+    bool force_exact = false;  // the level is taken up again on the exact arithmetic (recheck queue overflow of a tmaj level)
 };
 
 static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
@@ -246,8 +248,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.cls = c;
             sp.chunk = (c == 0) ? pl.chunk0 : chunk;
             sp.item_cap = item_cap;
+            sp.validate = e->opt_validate;
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.pair_lds, cs));
+            else if (pl.tmaj && pl.use_fast && !exact_only)
+                CUSK_HIP(e, launch_sweep_tmaj(a.mode, l, sp, c, cs));
             else if (pl.use_fast && !exact_only && !het && e->opt_vec && !e->opt_validate && c < kNumClasses - 1 &&
                      sweep_vec_lds_bytes(c) <= kLdsLimit && l < kVecMaxLevel)
                 CUSK_HIP(e, launch_sweep_vec(a.mode, l, sp, c, c == 0 ? e->opt_vec_threads : kThreads, cs));
@@ -420,8 +425,14 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 const bool vec0 = (e->opt_fast != 0) && l >= 2 && l < kVecMaxLevel && th_l >= kThMinFilter && !het && e->opt_vec &&
                                   !e->opt_validate && staged_classes > 0;
                 plan[l].chunk0 = vec0 ? chunk0 : chunk;
+                // deep levels by unions T = S + Y: single threshold, symmetric matrix (the inverse-based form has no
+                // meaning for the two orientations of an asymmetric input), filter certified for this threshold
+                plan[l].tmaj = (e->opt_fast != 0) && !plan[l].force_exact && l >= std::max(2, e->opt_tmaj_min_level) && l <= kML &&
+                               th_l >= kThMinFilter && !het && symmetric && !sharded;
+                if (plan[l].tmaj) plan[l].chunk0 = chunk;
             }
             pa.chunk0 = plan[l].chunk0;
+            pa.Lsets = plan[l].tmaj ? l + 1 : l;
             pa.staged_classes = staged_classes;
             pa.pair_mode = ((l == 1) && !first_build && plan[l].use_pair && !plan[l].use_rows) ? 1 : 0;
             pa.cnt = dcnt + l;
@@ -517,7 +528,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 if (k >= 1 && e->hgate[k].seq == run_seq && e->hgate[k].active) pl.maxdeg_bound = std::min(maxdeg1, e->hgate[k].maxdeg);
                 pl.staged_classes = staged_classes;
             }
-            pl.use_fast = (e->opt_fast != 0) && (l >= 2);
+            pl.use_fast = (e->opt_fast != 0) && (l >= 2) && !pl.force_exact;
             // 2. the neighbour lists (no host dependency)
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), off_l, e->nbr[cs].as<int>(),
                                         (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr, n, words,
@@ -625,8 +636,17 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         if (!sharded && last_ran >= 2 && plan[last_ran].use_fast && !plan[last_ran].redone &&
             e->hcnt[last_ran].qcount > (unsigned long long)e->opt_queue_cap)
         {
-            redo = last_ran;
-            start = last_ran + 1;
+            if (plan[last_ran].tmaj)
+            {  // its work items count unions, not conditioning sets: plan the level again for the exact kernels
+                plan[last_ran].force_exact = true;
+                local.exact_fallbacks++;
+                start = last_ran;
+            }
+            else
+            {
+                redo = last_ran;
+                start = last_ran + 1;
+            }
         }
         else if (ended && e->hcnt[ended].overflow)
             return fail(e, CUSK_ERR_OVERFLOW,
@@ -854,6 +874,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)
         e->opt_chunk = value;
+    else if (k == "tmaj_min_level")
+        e->opt_tmaj_min_level = (int)value;
     else if (k == "hostprof")
         e->opt_hostprof = (int)value;
     else if (k == "chunk0" && value >= 64)

@@ -80,6 +80,7 @@ struct SweepParams
     unsigned long long *slots;  // this level's kCounterSlots x 4 spread counters: tests, subsets, removed, violations
     RecheckEntry *queue;
     unsigned long long qcap;
+    int validate;  // sweep_tmaj: check every certified verdict against double precision (cusk_stats.violations)
 };
 
 struct FinalizeParams
@@ -239,6 +240,9 @@ hipError_t launch_rec_compact(const int *rec_l, const int *rec_x, const int *rec
                               long long out_stride, hipStream_t st);
 // sweep_fast.hip
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st);
+// sweep_tmaj.hip: deep levels by the union T = S + Y (one inverse per l + 1 tests); work items count (l + 1)-subsets
+hipError_t launch_sweep_tmaj(int mode, int L, const SweepParams &p, int cls, hipStream_t st);
+constexpr int kTmajMinLevel = 9;
 // sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
 hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, int threads, hipStream_t st);
 // workgroups of a persistent sweep launch: what the chip holds at once for this kernel (occupancy x CUs), cached
@@ -260,6 +264,7 @@ struct PlanArgs
     int *off;
     int2 *items[kNumClasses];
     int n, L;
+    int Lsets;  // size of the subsets the work items count: L, or L + 1 where the level is swept by unions T = S + Y (sweep_tmaj.hip)
     const unsigned long long *binom;
     unsigned long long chunk, chunk0;  // conditioning sets per work item: classes >= 1, class 0
     int staged_classes, pair_mode;

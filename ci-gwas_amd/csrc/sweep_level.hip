@@ -474,7 +474,7 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
     {
         // work units of the row: conditioning sets, or unordered neighbour pairs for the pair kernel
         const unsigned long long nc = a.pair_mode ? (unsigned long long)d * (d - 1) / 2
-                                                  : (L == 1 ? (unsigned long long)d : a.binom[(size_t)d * kBinomStride + L]);
+                                                  : (L == 1 ? (unsigned long long)d : a.binom[(size_t)d * kBinomStride + a.Lsets]);
         if (nc >= (1ull << 62))
             ovf = true;
         else if (a.shard_world == 1 || row % a.shard_world == a.shard_rank)

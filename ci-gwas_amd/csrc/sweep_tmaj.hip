@@ -1,0 +1,419 @@
+// sweep_tmaj.hip -- deep levels of the sweep (l >= kTmajMinLevel, single threshold): enumeration by the UNION
+// T = S + {Y} instead of by the conditioning set S.
+//
+// The S-major kernels (sweep_vec / sweep_fast) pay one forward substitution of O(l^2 / 2) per test (X, Y | S).  All
+// l + 1 tests whose variables are the same l + 1 neighbours T of X -- (X, t | T \ t) for t in T -- are entries of ONE
+// inverse, P = C[T + X, T + X]^-1:   rho(X, t | T \ t)^2 = P_tX^2 / (P_tt P_XX).   Taking the (l + 1)-subsets T of the
+// neighbour list in lexicographic order, a lane keeps M = C[Q, Q]^-1 of the first l - 1 members Q of T in registers
+// (explicit symmetric inverse, built by bordering whenever Q changes: every ~8th set at l = 14, d = 39) together
+// with M C[Q, X] and M C[Q, c1]; per set it forms M C[Q, c2] (one symmetric matrix-vector product, (l-1)^2 FMAs),
+// the 3 x 3 Schur complement of Q in {c1, c2, X} and its inverse W, and reads the l + 1 tests off
+//     P_qX = -(U W)_qX,   P_qq = M_qq + u_q W u_q^T   (q in Q; U = M C[Q, {c1, c2, X}]),     P_cX = W_cX, P_cc = W_cc.
+// About 50 fp32 operations per test at l = 14 instead of ~150.  Every (S, Y) pair is visited exactly once (T = S + Y), the
+// selection rule is unchanged: the lowest full-list rank of S per slot of Y (atomic minimum), computed only when a
+// test passes.
+//
+// As in ci_fast.h the result is a FILTER: a verdict is certified only outside the guard band rho^2 vs t^2 (1 +- kBeta)
+// and only when every pivot met on the way (bordering pivots of M, the three pivots of the Schur complement) and the
+// two conditional variances 1 / P_tt, 1 / P_XX are at least kCondMin; everything else is queued for recheck_kernel
+// (the reference's arithmetic).  An explicit inverse is less forgiving than a Cholesky solve (forward error ~ kappa eps
+// on the entries of M), so the `validate` option checks every certified verdict of this kernel against a
+// double-precision evaluation of the same test with three quarters of the band as margin (cusk_stats.violations).
+#include <algorithm>
+
+#include "ci_fast.h"
+#include "sweep_stage.h"
+
+namespace cusk {
+
+// lexicographic rank of the ascending positions s[0..L) among the L-subsets of d positions
+template <int L>
+__device__ __forceinline__ unsigned long long rank_comb(const int *s, int d, const unsigned long long *__restrict__ binom)
+{
+    unsigned long long r = binom[(size_t)d * kBinomStride + L] - 1ull;
+#pragma unroll
+    for (int i = 0; i < L; i++)
+    {
+        const int a = d - 1 - s[i], b = L - i;
+        if (a >= b) r -= binom[(size_t)a * kBinomStride + b];
+    }
+    return r;
+}
+
+// double-precision rho^2 of (X ; Y | S) from the staged sub-matrix (validate option only): Cholesky of C[S, S],
+// forward substitution of the two right-hand sides
+template <int L, typename RV>
+__device__ __noinline__ double rho2_f64(const RV &rv, int d, const int *S, int k2)
+{
+    double F[L * L];
+    double a[L], b[L];
+    for (int i = 0; i < L; i++)
+    {
+        double dii = 1.0;
+        for (int j = 0; j < i; j++)
+        {
+            double s = (double)rv.cval(S[i], S[j]);
+            for (int k = 0; k < j; k++) s -= F[i * L + k] * F[j * L + k];
+            F[i * L + j] = s / F[j * L + j];
+            dii -= F[i * L + j] * F[i * L + j];
+        }
+        F[i * L + i] = sqrt(dii);
+        double sa = (double)rv.cval(d, S[i]), sb = (double)rv.cval(k2, S[i]);
+        for (int k = 0; k < i; k++)
+        {
+            sa -= F[i * L + k] * a[k];
+            sb -= F[i * L + k] * b[k];
+        }
+        a[i] = sa / F[i * L + i];
+        b[i] = sb / F[i * L + i];
+    }
+    double h00 = 1.0, h11 = 1.0, h01 = (double)rv.cval(d, k2);
+    for (int i = 0; i < L; i++)
+    {
+        h00 -= a[i] * a[i];
+        h11 -= b[i] * b[i];
+        h01 -= a[i] * b[i];
+    }
+    return h01 * h01 / (h00 * h11);
+}
+
+// Register budget: the inverse of C[Q, Q] is (l - 1) l / 2 registers; without a bound the compiler takes 126 VGPRs at
+// l = 7, 152 at 9, 204 at 12, 247 at 13 and 14.  Four waves per SIMD up to level 7, three up to level 12 (a few dozen
+// spilled values at 10 - 12), two beyond.
+template <int L, int MODE, bool STAGED, bool VALIDATE>
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L <= 7 ? 4 : (L <= 12 ? 3 : 2))))
+sweep_tmaj_kernel(SweepParams p)
+{
+    static_assert(L >= 2 && L + 1 < kBinomStride, "T = S + Y has l + 1 members");
+    constexpr int NT = L + 1;  // members of T
+    constexpr int NQ = L - 1;  // members of Q = the first l - 1 of T; c1 = T[NQ], c2 = T[NQ + 1]
+    constexpr int NM = NQ * (NQ + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ unsigned long long s_cnt[4];
+    if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0ull;
+    unsigned long long ntests = 0, nsub = 0, nrem = 0, nbad = 0;
+    const long long nitems = level_items(p);
+    constexpr long long kBatch = 8;
+    __shared__ long long s_next;
+    const bool dynamic = nitems > (long long)gridDim.x * 64;
+    long long it = dynamic ? 0 : (long long)blockIdx.x, batch_end = 0;
+    bool first = true;
+    const float t2 = p.t2;
+    const float t2lo = t2 * (1.0f - kBeta), t2hi = t2 * (1.0f + kBeta);
+    constexpr float kVarMax = 1.0f / kCondMin;  // P_tt <= 64  <=>  conditional variance >= 1/64
+    for (;;)
+    {
+    if (dynamic && it >= batch_end)
+    {
+        __syncthreads();
+        if (threadIdx.x == 0) s_next = (long long)atomicAdd(&p.cnt->next_item[p.cls], (unsigned long long)kBatch);
+        __syncthreads();
+        it = s_next;
+        batch_end = it + kBatch;
+        first = true;
+    }
+    if (it >= nitems) break;
+    if (!first) __syncthreads();  // the previous item's readers are done with the staged copy
+    first = false;
+    const long long it_cur = it;
+    it = dynamic ? it + 1 : it + gridDim.x;
+    const int2 item = p.items[it_cur];
+    RowView<MODE, false, STAGED> rv(p, item.x, smem);
+    rv.stage();
+    const int d = rv.d;
+    const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + NT], item.y, p.chunk);
+    [[maybe_unused]] const int tiX = (MODE == 1) ? rv.tix(d) : 0;
+
+    if (rr.lo < rr.hi)
+    {
+        int idx[NT];
+        unrank_comb<NT>(rr.lo, d, p.binom, idx);
+        float M[NM];               // symmetric inverse of C[Q, Q], packed rows: (i, j), j <= i at i (i + 1) / 2 + j
+        float uX[NQ], u1[NQ];      // M C[Q, X], M C[Q, c1]
+        float sXX = 1.0f, s11 = 1.0f, s1X = 0.0f;
+        bool illQ = false;
+        auto Mat = [&](int i, int j) -> float & { return (i >= j) ? M[i * (i + 1) / 2 + j] : M[j * (j + 1) / 2 + i]; };
+        int changed = 0;  // first member of T that differs from the lane's previous set
+        for (unsigned long long rank = rr.lo; rank < rr.hi; rank++)
+        {
+            nsub++;
+            if (changed < NQ)
+            {
+                // ---- M = C[Q, Q]^-1 by bordering, pivot sigma_k = 1 - h^T M_k h = Var(q_k | q_0 .. q_k-1) ----
+                bool bad = false;
+#pragma unroll
+                for (int k = 0; k < NQ; k++)
+                {
+                    float h[NQ > 0 ? NQ : 1], v[NQ > 0 ? NQ : 1];
+#pragma unroll
+                    for (int j = 0; j < k; j++) h[j] = rv.cval(idx[k], idx[j]);
+                    float sig = 1.0f;
+#pragma unroll
+                    for (int i = 0; i < k; i++)
+                    {
+                        float s = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < k; j++) s = __builtin_fmaf(Mat(i, j), h[j], s);
+                        v[i] = s;
+                        sig = __builtin_fmaf(-h[i], s, sig);
+                    }
+                    bad = bad || !(sig >= kCondMin);
+                    const float inv = __frcp_rn(sig);
+#pragma unroll
+                    for (int i = 0; i < k; i++)
+                    {
+                        const float vi = v[i] * inv;
+#pragma unroll
+                        for (int j = 0; j <= i; j++) Mat(i, j) = __builtin_fmaf(vi, v[j], Mat(i, j));
+                        Mat(k, i) = -vi;
+                    }
+                    Mat(k, k) = inv;
+                }
+                illQ = bad;
+                float gx[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; j++) gx[j] = rv.cval(d, idx[j]);
+                sXX = 1.0f;
+#pragma unroll
+                for (int i = 0; i < NQ; i++)
+                {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), gx[j], s);
+                    uX[i] = s;
+                    sXX = __builtin_fmaf(-gx[i], s, sXX);
+                }
+            }
+            const int c1 = idx[NQ], c2 = idx[NQ + 1];
+            if (changed <= NQ)
+            {
+                float g1[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; j++) g1[j] = rv.cval(c1, idx[j]);
+                s11 = 1.0f;
+                s1X = rv.cval(d, c1);
+#pragma unroll
+                for (int i = 0; i < NQ; i++)
+                {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), g1[j], s);
+                    u1[i] = s;
+                    s11 = __builtin_fmaf(-g1[i], s, s11);
+                    s1X = __builtin_fmaf(-g1[i], uX[i], s1X);
+                }
+            }
+            // ---- this set: u2 = M C[Q, c2], Schur complement of Q in {c1, c2, X} ----
+            float u2[NQ];
+            float s12 = rv.cval(c2, c1), s22 = 1.0f, s2X = rv.cval(d, c2);
+            {
+                float g2[NQ];
+#pragma unroll
+                for (int j = 0; j < NQ; j++) g2[j] = rv.cval(c2, idx[j]);
+#pragma unroll
+                for (int i = 0; i < NQ; i++)
+                {
+                    float s = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), g2[j], s);
+                    u2[i] = s;
+                    s22 = __builtin_fmaf(-g2[i], s, s22);
+                    s12 = __builtin_fmaf(-g2[i], u1[i], s12);
+                    s2X = __builtin_fmaf(-g2[i], uX[i], s2X);
+                }
+            }
+            // W = (L D L^T)^-1 of [[s11, s12, s1X], [s12, s22, s2X], [s1X, s2X, sXX]]
+            const float d1 = s11, r1 = __frcp_rn(d1);
+            const float l21 = s12 * r1, l31 = s1X * r1;
+            const float d2 = __builtin_fmaf(-l21, s12, s22), r2 = __frcp_rn(d2);
+            const float tt = __builtin_fmaf(-l21, s1X, s2X);
+            const float l32 = tt * r2;
+            const float d3 = __builtin_fmaf(-l32, tt, __builtin_fmaf(-l31, s1X, sXX)), r3 = __frcp_rn(d3);
+            const bool ill = illQ || !(d1 >= kCondMin) || !(d2 >= kCondMin) || !(d3 >= kCondMin);
+            const float m31 = __builtin_fmaf(l21, l32, -l31), m32 = -l32;
+            const float WXX = r3, W2X = m32 * r3, W1X = m31 * r3;
+            const float W22 = __builtin_fmaf(m32, W2X, r2);
+            const float W12 = __builtin_fmaf(m31, W2X, -l21 * r2);
+            const float W11 = __builtin_fmaf(m31, W1X, __builtin_fmaf(l21 * l21, r2, r1));
+            // time-index rule of the hetcor engine: a test is skipped when its conditioning set holds a variable later
+            // than both X and Y; the two largest time indices of T settle that for every choice of Y
+            [[maybe_unused]] int ti_top = 0, ti_second = 0, ti_top_count = 0;
+            if constexpr (MODE == 1)
+            {
+                ti_top = -2147483647;
+                ti_second = -2147483647;
+#pragma unroll
+                for (int a = 0; a < NT; a++)
+                {
+                    const int t = rv.tix(idx[a]);
+                    if (t > ti_top)
+                    {
+                        ti_second = ti_top;
+                        ti_top = t;
+                        ti_top_count = 1;
+                    }
+                    else if (t == ti_top)
+                        ti_top_count++;
+                    else if (t > ti_second)
+                        ti_second = t;
+                }
+            }
+            // ---- the l + 1 tests of the set: member j of T is Y, the others are S ----
+            const float rXX = t2lo * WXX, rXXhi = t2hi * WXX;
+            unsigned passm = 0u, unsurem = 0u;
+#pragma unroll
+            for (int j = 0; j < NT; j++)
+            {
+                float num, pyy;
+                if (j < NQ)
+                {
+                    const float a = __builtin_fmaf(u1[j], W1X, __builtin_fmaf(u2[j], W2X, uX[j] * WXX));
+                    const float v1 = __builtin_fmaf(u1[j], W11, __builtin_fmaf(u2[j], W12, uX[j] * W1X));
+                    const float v2 = __builtin_fmaf(u1[j], W12, __builtin_fmaf(u2[j], W22, uX[j] * W2X));
+                    pyy = __builtin_fmaf(u1[j], v1, __builtin_fmaf(u2[j], v2, __builtin_fmaf(uX[j], a, Mat(j, j))));
+                    num = a;
+                }
+                else if (j == NQ)
+                {
+                    num = W1X;
+                    pyy = W11;
+                }
+                else
+                {
+                    num = W2X;
+                    pyy = W22;
+                }
+                const float lhs = num * num;
+                const bool okc = (pyy <= kVarMax) && (WXX <= kVarMax) && (pyy > 0.0f);
+                const bool pass = okc && (lhs < rXX * pyy);
+                const bool fail = okc && (lhs > rXXhi * pyy);
+                if (pass) passm |= 1u << j;
+                if (!pass && !fail) unsurem |= 1u << j;
+            }
+            if (ill)
+            {
+                passm = 0u;
+                unsurem = (1u << NT) - 1u;
+            }
+            if constexpr (MODE == 1)
+            {
+                // drop the tests the time-index rule excludes, and those whose edge is gone already
+                unsigned skip = 0u;
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                {
+                    const int tj = rv.tix(idx[j]);
+                    const int tmaxS = (tj == ti_top && ti_top_count == 1) ? ti_second : ti_top;
+                    if (tmaxS > max(tiX, tj)) skip |= 1u << j;
+                }
+                passm &= ~skip;
+                unsurem &= ~skip;
+                ntests += NT - __popc(skip);
+            }
+            else
+                ntests += NT;
+            if (VALIDATE && !ill)
+            {  // certified verdicts against double precision, three quarters of the band as margin
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                {
+                    if ((unsurem >> j) & 1u) continue;
+                    int S[L];
+#pragma unroll
+                    for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
+                    const double r2d = rho2_f64<L>(rv, d, S, idx[j]);
+                    const bool pj = (passm >> j) & 1u;
+                    if (pj ? !(r2d < (double)t2 * (1.0 - 0.25 * (double)kBeta)) : !(r2d > (double)t2 * (1.0 + 0.25 * (double)kBeta))) nbad++;
+                }
+            }
+            if ((passm | unsurem) != 0u)
+            {  // rare: leaves the straight line (static member indices: the set stays in registers)
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                {
+                    if (!(((passm | unsurem) >> j) & 1u)) continue;
+                    int S[L];
+#pragma unroll
+                    for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
+                    const int k2 = idx[j];
+                    const unsigned long long srank = rank_comb<L>(S, d, p.binom);
+                    if ((passm >> j) & 1u)
+                    {
+                        if (rv.separate(k2, srank)) nrem++;
+                    }
+                    else if (rv.live(k2, srank))
+                    {  // uncertain, and not yet decided by a lower set: the exact path
+                        const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
+                        if (qi < p.qcap)
+                        {
+                            RecheckEntry en;
+                            en.x = rv.X;
+                            en.k2 = k2;
+                            en.rank = srank;
+                            p.queue[qi] = en;
+                        }
+                    }
+                }
+            }
+            changed = next_comb_pos<NT>(idx, d);
+            if (changed < 0) break;
+        }
+    }
+    }  // work items
+    __syncthreads();
+    flush_counters(s_cnt, p.slots, ntests, nsub, MODE == 1 ? nrem : 0ull, nbad);
+}
+
+template <int L, int MODE>
+static hipError_t launch_tmaj_L(const SweepParams &p, int cls, hipStream_t st)
+{
+    if (cls < kNumClasses - 1)
+    {
+        const size_t lds = lds_layout(kClassCap[cls], false).total;
+        // the validating build exists for the Skeleton engine's staged classes (a device function call in the kernel
+        // costs the other builds their registers)
+        auto kfn = (MODE == 0 && p.validate) ? sweep_tmaj_kernel<L, MODE, true, (MODE == 0)> : sweep_tmaj_kernel<L, MODE, true, false>;
+        if (lds > 64 * 1024)
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+        }
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
+    }
+    else
+    {
+        auto kfn = sweep_tmaj_kernel<L, MODE, false, false>;
+        const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, 16),
+                                                            std::max<long long>(p.item_cap, 1));
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), 16, st, p);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_sweep_tmaj(int mode, int L, const SweepParams &p, int cls, hipStream_t st)
+{
+    switch (L)
+    {
+#define CUSK_CASE(LL) \
+    case LL: return mode == 0 ? launch_tmaj_L<LL, 0>(p, cls, st) : launch_tmaj_L<LL, 1>(p, cls, st);
+        CUSK_CASE(2)
+        CUSK_CASE(3)
+        CUSK_CASE(4)
+        CUSK_CASE(5)
+        CUSK_CASE(6)
+        CUSK_CASE(7)
+        CUSK_CASE(8)
+        CUSK_CASE(9)
+        CUSK_CASE(10)
+        CUSK_CASE(11)
+        CUSK_CASE(12)
+        CUSK_CASE(13)
+        CUSK_CASE(14)
+#undef CUSK_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace cusk
