@@ -23,6 +23,10 @@ constexpr unsigned long long kNone = ~0ull;
 constexpr int kNumClasses = 5;
 constexpr int kClassCap[kNumClasses] = {39, 63, 127, 191, 1 << 30};
 constexpr int kThreads = 256;
+// first level swept by unions T = S + Y (sweep_tmaj.hip); measured on stage two of the 10k block (d = 39): level 5
+// 0.32 ms against 0.21 ms for the set-major float2 kernel, level 6 0.83 against 0.94, level 7 2.1 against 4.2, level 8
+// 6.7 against 16.8, level 14 1.3 s against 3.2 s
+constexpr int kTmajMinLevelDefault = 6;
 constexpr int kCounterSlots = 512;  // per-workgroup counter atomics are spread over this many slots
 constexpr size_t kLdsLimit = 160 * 1024;
 
@@ -123,7 +127,7 @@ struct cusk_engine
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     int opt_hostprof = 0;
-    int opt_tmaj_min_level = 9;  // first level swept by unions T = S + Y (sweep_tmaj.hip); 99 = never
+    int opt_tmaj_min_level = cusk::kTmajMinLevelDefault;  // first level swept by unions T = S + Y (sweep_tmaj.hip); 99 = never
     long long opt_chunk = 2048;
     long long opt_chunk0 = 512;   // conditioning sets per work item of the first degree class
     int opt_vec_threads = 64;     // workgroup size of sweep_vec_kernel for the first degree class (64 / 128 / 256)

@@ -16,6 +16,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "sweep_common.h"
@@ -809,6 +810,21 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         return CUSK_ERR_HIP;
     }
     *out = e;
+    // kernel experiments without touching the caller: CUSK_OPTIONS="key=value,key=value" (cusk_engine_set_option pairs)
+    if (const char *env = std::getenv("CUSK_OPTIONS"))
+    {
+        std::string all(env);
+        size_t pos = 0;
+        while (pos < all.size())
+        {
+            const size_t end = std::min(all.find(',', pos), all.size());
+            const std::string kv = all.substr(pos, end - pos);
+            const size_t eq = kv.find('=');
+            if (eq != std::string::npos)
+                (void)cusk_engine_set_option(e, kv.substr(0, eq).c_str(), std::atoll(kv.c_str() + eq + 1));
+            pos = end + 1;
+        }
+    }
     return CUSK_OK;
 }
 

@@ -242,7 +242,15 @@ hipError_t launch_rec_compact(const int *rec_l, const int *rec_x, const int *rec
 hipError_t launch_sweep_fast(int mode, bool het, int L, bool validate, const SweepParams &p, int cls, hipStream_t st);
 // sweep_tmaj.hip: deep levels by the union T = S + Y (one inverse per l + 1 tests); work items count (l + 1)-subsets
 hipError_t launch_sweep_tmaj(int mode, int L, const SweepParams &p, int cls, hipStream_t st);
-constexpr int kTmajMinLevel = 9;
+// union-major levels, work decomposition shared by the plan kernel and the sweep: prefixes (the first l - 1 members of a
+// union, the last of them at list position s) per lane of a work item, so that an item holds about `chunk` unions
+__host__ __device__ inline int tmaj_prefixes_per_lane(int d, int s, unsigned long long chunk)
+{
+    const unsigned long long r = (unsigned long long)(d - 1 - s);
+    const unsigned long long pairs = r * (r - 1ull) / 2ull;  // s < c1 < c2 < d
+    const unsigned long long k = chunk / ((unsigned long long)kThreads * (pairs ? pairs : 1ull));
+    return (int)(k < 1ull ? 1ull : (k > 64ull ? 64ull : k));
+}
 // sweep_vec.hip: vectorised fast sweep (l >= 2, single threshold, staged classes only)
 hipError_t launch_sweep_vec(int mode, int L, const SweepParams &p, int cls, int threads, hipStream_t st);
 // workgroups of a persistent sweep launch: what the chip holds at once for this kernel (occupancy x CUs), cached

@@ -483,7 +483,20 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
             while (d > kClassCap[cls]) cls++;
             if (cls >= a.staged_classes) cls = kNumClasses - 1;
             const unsigned long long ch = (cls == 0) ? a.chunk0 : a.chunk;
-            nchunks = (int)((nc + ch - 1) / ch);
+            if (a.Lsets == L + 1 && L >= 2)
+            {  // union-major level (sweep_tmaj.hip): items per end position s of the prefix
+                const int np = L - 2;
+                long long tot = 0;
+                for (int s = np; s <= d - 3; s++)
+                {
+                    const unsigned long long nP = (np == 0) ? 1ull : a.binom[(size_t)s * kBinomStride + np];
+                    const unsigned long long per = (unsigned long long)kThreads * tmaj_prefixes_per_lane(d, s, ch);
+                    tot += (long long)((nP + per - 1ull) / per);
+                }
+                nchunks = (int)min(tot, (long long)0x7fffffff);
+            }
+            else
+                nchunks = (int)((nc + ch - 1) / ch);
         }
     }
     const bool wave_ovf = __ballot(ovf) != 0ull;

@@ -1,11 +1,10 @@
-// sweep_tmaj.hip -- deep levels of the sweep (l >= kTmajMinLevel, single threshold): enumeration by the UNION
+// sweep_tmaj.hip -- deep levels of the sweep (l >= kTmajMinLevelDefault = 6, single threshold): enumeration by the UNION
 // T = S + {Y} instead of by the conditioning set S.
 //
 // The S-major kernels (sweep_vec / sweep_fast) pay one forward substitution of O(l^2 / 2) per test (X, Y | S).  All
 // l + 1 tests whose variables are the same l + 1 neighbours T of X -- (X, t | T \ t) for t in T -- are entries of ONE
-// inverse, P = C[T + X, T + X]^-1:   rho(X, t | T \ t)^2 = P_tX^2 / (P_tt P_XX).   Taking the (l + 1)-subsets T of the
-// neighbour list in lexicographic order, a lane keeps M = C[Q, Q]^-1 of the first l - 1 members Q of T in registers
-// (explicit symmetric inverse, built by bordering whenever Q changes: every ~8th set at l = 14, d = 39) together
+// inverse, P = C[T + X, T + X]^-1:   rho(X, t | T \ t)^2 = P_tX^2 / (P_tt P_XX).   A lane keeps M = C[Q, Q]^-1 of the
+// first l - 1 members Q of T in registers (explicit symmetric inverse, built by bordering once per Q) together
 // with M C[Q, X] and M C[Q, c1]; per set it forms M C[Q, c2] (one symmetric matrix-vector product, (l-1)^2 FMAs),
 // the 3 x 3 Schur complement of Q in {c1, c2, X} and its inverse W, and reads the l + 1 tests off
 //     P_qX = -(U W)_qX,   P_qq = M_qq + u_q W u_q^T   (q in Q; U = M C[Q, {c1, c2, X}]),     P_cX = W_cX, P_cc = W_cc.
@@ -77,16 +76,25 @@ __device__ __noinline__ double rho2_f64(const RV &rv, int d, const int *S, int k
     return h01 * h01 / (h00 * h11);
 }
 
-// Register budget: the inverse of C[Q, Q] is (l - 1) l / 2 registers; without a bound the compiler takes 126 VGPRs at
-// l = 7, 152 at 9, 204 at 12, 247 at 13 and 14.  Four waves per SIMD up to level 7, three up to level 12 (a few dozen
-// spilled values at 10 - 12), two beyond.
+// Work decomposition (second form).  A lane that walks its own lexicographic stream of unions rebuilds M whenever ITS
+// prefix Q changes -- every seventh step at l = 14, but at a different step in every lane, so a wavefront paid the rebuild
+// on every step (measured: 2,800 instructions per set instead of ~800).  The control flow is made uniform instead:
+// a work item holds prefixes Q = P + {s} that all END AT THE SAME LIST POSITION s (P = an (l - 2)-subset of the positions
+// below s, one per lane, k of them in turn); every lane then runs the same two loops over the pairs s < c1 < c2 < d.
+// M is built once per prefix, by all lanes at the same time, and serves C(d - 1 - s, 2) unions; no branch of the
+// arithmetic depends on the lane.  Items of a row: sum over s of ceil(C(s, l - 2) / (256 k(s))), k(s) chosen so that an
+// item holds about `chunk` unions (tmaj_prefixes_per_lane, shared with the plan kernel).
+//
+// Register budget: the inverse of C[Q, Q] is (l - 1) l / 2 registers; four waves per SIMD up to level 7, three up to
+// level 10, two beyond (at three, levels 11 and 12 spilled 60 - 85 values into the loop and ran slower than level 13).
 template <int L, int MODE, bool STAGED, bool VALIDATE>
-__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L <= 7 ? 4 : (L <= 12 ? 3 : 2))))
+__global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L <= 7 ? 4 : (L <= 10 ? 3 : 2))))
 sweep_tmaj_kernel(SweepParams p)
 {
     static_assert(L >= 2 && L + 1 < kBinomStride, "T = S + Y has l + 1 members");
     constexpr int NT = L + 1;  // members of T
     constexpr int NQ = L - 1;  // members of Q = the first l - 1 of T; c1 = T[NQ], c2 = T[NQ + 1]
+    constexpr int NP = NQ - 1; // members of Q below its last one
     constexpr int NM = NQ * (NQ + 1) / 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __shared__ unsigned long long s_cnt[4];
@@ -121,242 +129,294 @@ sweep_tmaj_kernel(SweepParams p)
     RowView<MODE, false, STAGED> rv(p, item.x, smem);
     rv.stage();
     const int d = rv.d;
-    const RankRange rr = lane_ranks(p.binom[(size_t)d * kBinomStride + NT], item.y, p.chunk);
     [[maybe_unused]] const int tiX = (MODE == 1) ? rv.tix(d) : 0;
-
-    if (rr.lo < rr.hi)
+    // ---- which s, which prefixes: item.y counts the row's items in the order s = NP, NP + 1, ... ----
+    int s = NP, kper = 1;
+    unsigned long long nP = 1ull;
+    long long rel = item.y;
+    for (;; s++)
     {
-        int idx[NT];
-        unrank_comb<NT>(rr.lo, d, p.binom, idx);
-        float M[NM];               // symmetric inverse of C[Q, Q], packed rows: (i, j), j <= i at i (i + 1) / 2 + j
-        float uX[NQ], u1[NQ];      // M C[Q, X], M C[Q, c1]
-        float sXX = 1.0f, s11 = 1.0f, s1X = 0.0f;
-        bool illQ = false;
-        auto Mat = [&](int i, int j) -> float & { return (i >= j) ? M[i * (i + 1) / 2 + j] : M[j * (j + 1) / 2 + i]; };
-        int changed = 0;  // first member of T that differs from the lane's previous set
-        for (unsigned long long rank = rr.lo; rank < rr.hi; rank++)
+        nP = (NP == 0) ? 1ull : p.binom[(size_t)s * kBinomStride + NP];
+        kper = tmaj_prefixes_per_lane(d, s, p.chunk);
+        const long long ni = (long long)((nP + (unsigned long long)kThreads * kper - 1ull) / ((unsigned long long)kThreads * kper));
+        if (rel < ni || s >= d - 3) break;
+        rel -= ni;
+    }
+    const unsigned long long r_lo = ((unsigned long long)rel * kThreads + threadIdx.x) * (unsigned long long)kper;
+
+    int idx[NT];
+    idx[NQ - 1] = s;
+    [[maybe_unused]] int pidx[NP > 0 ? NP : 1];
+    for (int kk = 0; kk < kper; kk++)
+    {
+        const bool act = (r_lo + kk < nP);  // lanes past the last prefix repeat prefix 0 with their results masked
+        if constexpr (NP > 0)
         {
-            nsub++;
-            if (changed < NQ)
+            if (kk == 0 || !act)
+                unrank_comb<NP>(act ? r_lo + kk : 0ull, s, p.binom, pidx);
+            else
+                (void)next_comb_pos<NP>(pidx, s);
+#pragma unroll
+            for (int a = 0; a < NP; a++) idx[a] = pidx[a];
+        }
+        // ---- M = C[Q, Q]^-1 by bordering, pivot sigma_k = 1 - h^T M_k h = Var(q_k | q_0 .. q_k-1) ----
+        float M[NM];  // symmetric, packed rows: (i, j), j <= i at i (i + 1) / 2 + j
+        auto Mat = [&](int i, int j) -> float & { return (i >= j) ? M[i * (i + 1) / 2 + j] : M[j * (j + 1) / 2 + i]; };
+        bool illQ = false;
+#pragma unroll
+        for (int k = 0; k < NQ; k++)
+        {
+            float h[NQ], v[NQ];
+#pragma unroll
+            for (int j = 0; j < k; j++) h[j] = rv.cval(idx[k], idx[j]);
+            float sig = 1.0f;
+#pragma unroll
+            for (int i = 0; i < k; i++)
             {
-                // ---- M = C[Q, Q]^-1 by bordering, pivot sigma_k = 1 - h^T M_k h = Var(q_k | q_0 .. q_k-1) ----
-                bool bad = false;
+                float acc = 0.0f;
 #pragma unroll
-                for (int k = 0; k < NQ; k++)
-                {
-                    float h[NQ > 0 ? NQ : 1], v[NQ > 0 ? NQ : 1];
-#pragma unroll
-                    for (int j = 0; j < k; j++) h[j] = rv.cval(idx[k], idx[j]);
-                    float sig = 1.0f;
-#pragma unroll
-                    for (int i = 0; i < k; i++)
-                    {
-                        float s = 0.0f;
-#pragma unroll
-                        for (int j = 0; j < k; j++) s = __builtin_fmaf(Mat(i, j), h[j], s);
-                        v[i] = s;
-                        sig = __builtin_fmaf(-h[i], s, sig);
-                    }
-                    bad = bad || !(sig >= kCondMin);
-                    const float inv = __frcp_rn(sig);
-#pragma unroll
-                    for (int i = 0; i < k; i++)
-                    {
-                        const float vi = v[i] * inv;
-#pragma unroll
-                        for (int j = 0; j <= i; j++) Mat(i, j) = __builtin_fmaf(vi, v[j], Mat(i, j));
-                        Mat(k, i) = -vi;
-                    }
-                    Mat(k, k) = inv;
-                }
-                illQ = bad;
-                float gx[NQ];
-#pragma unroll
-                for (int j = 0; j < NQ; j++) gx[j] = rv.cval(d, idx[j]);
-                sXX = 1.0f;
-#pragma unroll
-                for (int i = 0; i < NQ; i++)
-                {
-                    float s = 0.0f;
-#pragma unroll
-                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), gx[j], s);
-                    uX[i] = s;
-                    sXX = __builtin_fmaf(-gx[i], s, sXX);
-                }
+                for (int j = 0; j < k; j++) acc = __builtin_fmaf(Mat(i, j), h[j], acc);
+                v[i] = acc;
+                sig = __builtin_fmaf(-h[i], acc, sig);
             }
-            const int c1 = idx[NQ], c2 = idx[NQ + 1];
-            if (changed <= NQ)
+            illQ = illQ || !(sig >= kCondMin);
+            const float inv = __frcp_rn(sig);
+#pragma unroll
+            for (int i = 0; i < k; i++)
+            {
+                const float vi = v[i] * inv;
+#pragma unroll
+                for (int j = 0; j <= i; j++) Mat(i, j) = __builtin_fmaf(vi, v[j], Mat(i, j));
+                Mat(k, i) = -vi;
+            }
+            Mat(k, k) = inv;
+        }
+        float uX[NQ];  // M C[Q, X]
+        float sXX = 1.0f;
+        {
+            float gx[NQ];
+#pragma unroll
+            for (int j = 0; j < NQ; j++) gx[j] = rv.cval(d, idx[j]);
+#pragma unroll
+            for (int i = 0; i < NQ; i++)
+            {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < NQ; j++) acc = __builtin_fmaf(Mat(i, j), gx[j], acc);
+                uX[i] = acc;
+                sXX = __builtin_fmaf(-gx[i], acc, sXX);
+            }
+        }
+        [[maybe_unused]] int tiQ_top = 0, tiQ_second = 0, tiQ_count = 0;
+        if constexpr (MODE == 1)
+        {  // the two largest time indices among Q (with the multiplicity of the largest)
+            tiQ_top = -2147483647;
+            tiQ_second = -2147483647;
+#pragma unroll
+            for (int a = 0; a < NQ; a++)
+            {
+                const int t = rv.tix(idx[a]);
+                if (t > tiQ_top)
+                {
+                    tiQ_second = tiQ_top;
+                    tiQ_top = t;
+                    tiQ_count = 1;
+                }
+                else if (t == tiQ_top)
+                    tiQ_count++;
+                else if (t > tiQ_second)
+                    tiQ_second = t;
+            }
+        }
+        for (int c1 = s + 1; c1 < d - 1; c1++)
+        {
+            idx[NQ] = c1;
+            float u1[NQ];  // M C[Q, c1]
+            float s11 = 1.0f, s1X = rv.cval(d, c1);
             {
                 float g1[NQ];
 #pragma unroll
                 for (int j = 0; j < NQ; j++) g1[j] = rv.cval(c1, idx[j]);
-                s11 = 1.0f;
-                s1X = rv.cval(d, c1);
 #pragma unroll
                 for (int i = 0; i < NQ; i++)
                 {
-                    float s = 0.0f;
+                    float acc = 0.0f;
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), g1[j], s);
-                    u1[i] = s;
-                    s11 = __builtin_fmaf(-g1[i], s, s11);
+                    for (int j = 0; j < NQ; j++) acc = __builtin_fmaf(Mat(i, j), g1[j], acc);
+                    u1[i] = acc;
+                    s11 = __builtin_fmaf(-g1[i], acc, s11);
                     s1X = __builtin_fmaf(-g1[i], uX[i], s1X);
                 }
             }
-            // ---- this set: u2 = M C[Q, c2], Schur complement of Q in {c1, c2, X} ----
-            float u2[NQ];
-            float s12 = rv.cval(c2, c1), s22 = 1.0f, s2X = rv.cval(d, c2);
+            const float d1 = s11, r1 = __frcp_rn(d1), l31 = s1X * r1;
+            const float sXX1 = __builtin_fmaf(-l31, s1X, sXX);  // Var(X | Q, c1)
+            const bool ill1 = illQ || !(d1 >= kCondMin);
+            for (int c2 = c1 + 1; c2 < d; c2++)
             {
-                float g2[NQ];
-#pragma unroll
-                for (int j = 0; j < NQ; j++) g2[j] = rv.cval(c2, idx[j]);
-#pragma unroll
-                for (int i = 0; i < NQ; i++)
+                idx[NQ + 1] = c2;
+                if (act) nsub++;
+                // ---- this union: u2 = M C[Q, c2], Schur complement of Q in {c1, c2, X} = L D L^T ----
+                float u2[NQ];
+                float s12 = rv.cval(c2, c1), s22 = 1.0f, s2X = rv.cval(d, c2);
                 {
-                    float s = 0.0f;
+                    float g2[NQ];
 #pragma unroll
-                    for (int j = 0; j < NQ; j++) s = __builtin_fmaf(Mat(i, j), g2[j], s);
-                    u2[i] = s;
-                    s22 = __builtin_fmaf(-g2[i], s, s22);
-                    s12 = __builtin_fmaf(-g2[i], u1[i], s12);
-                    s2X = __builtin_fmaf(-g2[i], uX[i], s2X);
-                }
-            }
-            // W = (L D L^T)^-1 of [[s11, s12, s1X], [s12, s22, s2X], [s1X, s2X, sXX]]
-            const float d1 = s11, r1 = __frcp_rn(d1);
-            const float l21 = s12 * r1, l31 = s1X * r1;
-            const float d2 = __builtin_fmaf(-l21, s12, s22), r2 = __frcp_rn(d2);
-            const float tt = __builtin_fmaf(-l21, s1X, s2X);
-            const float l32 = tt * r2;
-            const float d3 = __builtin_fmaf(-l32, tt, __builtin_fmaf(-l31, s1X, sXX)), r3 = __frcp_rn(d3);
-            const bool ill = illQ || !(d1 >= kCondMin) || !(d2 >= kCondMin) || !(d3 >= kCondMin);
-            const float m31 = __builtin_fmaf(l21, l32, -l31), m32 = -l32;
-            const float WXX = r3, W2X = m32 * r3, W1X = m31 * r3;
-            const float W22 = __builtin_fmaf(m32, W2X, r2);
-            const float W12 = __builtin_fmaf(m31, W2X, -l21 * r2);
-            const float W11 = __builtin_fmaf(m31, W1X, __builtin_fmaf(l21 * l21, r2, r1));
-            // time-index rule of the hetcor engine: a test is skipped when its conditioning set holds a variable later
-            // than both X and Y; the two largest time indices of T settle that for every choice of Y
-            [[maybe_unused]] int ti_top = 0, ti_second = 0, ti_top_count = 0;
-            if constexpr (MODE == 1)
-            {
-                ti_top = -2147483647;
-                ti_second = -2147483647;
+                    for (int j = 0; j < NQ; j++) g2[j] = rv.cval(c2, idx[j]);
 #pragma unroll
-                for (int a = 0; a < NT; a++)
-                {
-                    const int t = rv.tix(idx[a]);
-                    if (t > ti_top)
+                    for (int i = 0; i < NQ; i++)
                     {
-                        ti_second = ti_top;
-                        ti_top = t;
-                        ti_top_count = 1;
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < NQ; j++) acc = __builtin_fmaf(Mat(i, j), g2[j], acc);
+                        u2[i] = acc;
+                        s22 = __builtin_fmaf(-g2[i], acc, s22);
+                        s12 = __builtin_fmaf(-g2[i], u1[i], s12);
+                        s2X = __builtin_fmaf(-g2[i], uX[i], s2X);
                     }
-                    else if (t == ti_top)
-                        ti_top_count++;
-                    else if (t > ti_second)
-                        ti_second = t;
                 }
-            }
-            // ---- the l + 1 tests of the set: member j of T is Y, the others are S ----
-            const float rXX = t2lo * WXX, rXXhi = t2hi * WXX;
-            unsigned passm = 0u, unsurem = 0u;
-#pragma unroll
-            for (int j = 0; j < NT; j++)
-            {
-                float num, pyy;
-                if (j < NQ)
-                {
-                    const float a = __builtin_fmaf(u1[j], W1X, __builtin_fmaf(u2[j], W2X, uX[j] * WXX));
-                    const float v1 = __builtin_fmaf(u1[j], W11, __builtin_fmaf(u2[j], W12, uX[j] * W1X));
-                    const float v2 = __builtin_fmaf(u1[j], W12, __builtin_fmaf(u2[j], W22, uX[j] * W2X));
-                    pyy = __builtin_fmaf(u1[j], v1, __builtin_fmaf(u2[j], v2, __builtin_fmaf(uX[j], a, Mat(j, j))));
-                    num = a;
-                }
-                else if (j == NQ)
-                {
-                    num = W1X;
-                    pyy = W11;
-                }
-                else
-                {
-                    num = W2X;
-                    pyy = W22;
-                }
-                const float lhs = num * num;
-                const bool okc = (pyy <= kVarMax) && (WXX <= kVarMax) && (pyy > 0.0f);
-                const bool pass = okc && (lhs < rXX * pyy);
-                const bool fail = okc && (lhs > rXXhi * pyy);
-                if (pass) passm |= 1u << j;
-                if (!pass && !fail) unsurem |= 1u << j;
-            }
-            if (ill)
-            {
-                passm = 0u;
-                unsurem = (1u << NT) - 1u;
-            }
-            if constexpr (MODE == 1)
-            {
-                // drop the tests the time-index rule excludes, and those whose edge is gone already
-                unsigned skip = 0u;
+                const float l21 = s12 * r1;
+                const float d2 = __builtin_fmaf(-l21, s12, s22), r2 = __frcp_rn(d2);
+                const float tt = __builtin_fmaf(-l21, s1X, s2X);
+                const float l32 = tt * r2;
+                const float d3 = __builtin_fmaf(-l32, tt, sXX1), r3 = __frcp_rn(d3);  // Var(X | T) = 1 / P_XX
+                const bool ill = ill1 || !(d2 >= kCondMin) || !(d3 >= kCondMin);
+                // P_tX and P_tt of every member t through z = L^-1 u_t:  u^T W u = sum z_i^2 / d_i,  (W u)_X = z_3 / d_3
+                const float hiX = t2hi * r3, loX = t2lo * r3;
+                bool anytodo = ill;
+                float numv[NT], pyyv[NT];
 #pragma unroll
                 for (int j = 0; j < NT; j++)
                 {
-                    const int tj = rv.tix(idx[j]);
-                    const int tmaxS = (tj == ti_top && ti_top_count == 1) ? ti_second : ti_top;
-                    if (tmaxS > max(tiX, tj)) skip |= 1u << j;
-                }
-                passm &= ~skip;
-                unsurem &= ~skip;
-                ntests += NT - __popc(skip);
-            }
-            else
-                ntests += NT;
-            if (VALIDATE && !ill)
-            {  // certified verdicts against double precision, three quarters of the band as margin
-#pragma unroll
-                for (int j = 0; j < NT; j++)
-                {
-                    if ((unsurem >> j) & 1u) continue;
-                    int S[L];
-#pragma unroll
-                    for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
-                    const double r2d = rho2_f64<L>(rv, d, S, idx[j]);
-                    const bool pj = (passm >> j) & 1u;
-                    if (pj ? !(r2d < (double)t2 * (1.0 - 0.25 * (double)kBeta)) : !(r2d > (double)t2 * (1.0 + 0.25 * (double)kBeta))) nbad++;
-                }
-            }
-            if ((passm | unsurem) != 0u)
-            {  // rare: leaves the straight line (static member indices: the set stays in registers)
-#pragma unroll
-                for (int j = 0; j < NT; j++)
-                {
-                    if (!(((passm | unsurem) >> j) & 1u)) continue;
-                    int S[L];
-#pragma unroll
-                    for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
-                    const int k2 = idx[j];
-                    const unsigned long long srank = rank_comb<L>(S, d, p.binom);
-                    if ((passm >> j) & 1u)
+                    float z1, z2, z3, base;
+                    if (j < NQ)
                     {
-                        if (rv.separate(k2, srank)) nrem++;
+                        z1 = u1[j];
+                        z2 = __builtin_fmaf(-l21, z1, u2[j]);
+                        z3 = __builtin_fmaf(-l32, z2, __builtin_fmaf(-l31, z1, uX[j]));
+                        base = Mat(j, j);
                     }
-                    else if (rv.live(k2, srank))
-                    {  // uncertain, and not yet decided by a lower set: the exact path
-                        const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
-                        if (qi < p.qcap)
+                    else if (j == NQ)
+                    {  // t = c1: u = e_1
+                        z1 = 1.0f;
+                        z2 = -l21;
+                        z3 = __builtin_fmaf(l32, l21, -l31);
+                        base = 0.0f;
+                    }
+                    else
+                    {  // t = c2: u = e_2
+                        z1 = 0.0f;
+                        z2 = 1.0f;
+                        z3 = -l32;
+                        base = 0.0f;
+                    }
+                    const float num = z3 * r3;
+                    const float pyy = __builtin_fmaf(z3, num, __builtin_fmaf(z2 * z2, r2, __builtin_fmaf(z1 * z1, r1, base)));
+                    numv[j] = num;
+                    pyyv[j] = pyy;
+                    // certainly not separated: rho^2 above the band, conditional variance of t in range (a NaN anywhere
+                    // reads as "not certain")
+                    const bool fail = (num * num > hiX * pyy) && (pyy <= kVarMax) && (pyy > 0.0f);
+                    anytodo = anytodo || !fail;
+                }
+                if constexpr (MODE == 0)
+                {
+                    if (act) ntests += NT;
+                }
+                if (!(anytodo || VALIDATE || MODE == 1)) continue;
+                if (!act) continue;
+                // ---- rare (Skeleton engine): some test of the union passes or is uncertain ----
+                unsigned passm = 0u, unsurem = 0u;
+#pragma unroll
+                for (int j = 0; j < NT; j++)
+                {
+                    const float lhs = numv[j] * numv[j];
+                    const bool okc = (pyyv[j] <= kVarMax) && (r3 <= kVarMax) && (pyyv[j] > 0.0f);
+                    const bool pass = okc && (lhs < loX * pyyv[j]);
+                    const bool fail = okc && (lhs > hiX * pyyv[j]);
+                    if (pass) passm |= 1u << j;
+                    if (!pass && !fail) unsurem |= 1u << j;
+                }
+                if (ill)
+                {
+                    passm = 0u;
+                    unsurem = (1u << NT) - 1u;
+                }
+                if constexpr (MODE == 1)
+                {
+                    // time-index rule of the hetcor engine: a test is skipped when its conditioning set holds a variable
+                    // later than both X and Y; the two largest time indices of T settle that for every choice of Y
+                    int top = tiQ_top, second = tiQ_second, cnt = tiQ_count;
+#pragma unroll
+                    for (int a = NQ; a < NT; a++)
+                    {
+                        const int t = rv.tix(idx[a]);
+                        if (t > top)
                         {
-                            RecheckEntry en;
-                            en.x = rv.X;
-                            en.k2 = k2;
-                            en.rank = srank;
-                            p.queue[qi] = en;
+                            second = top;
+                            top = t;
+                            cnt = 1;
+                        }
+                        else if (t == top)
+                            cnt++;
+                        else if (t > second)
+                            second = t;
+                    }
+                    unsigned skip = 0u;
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                    {
+                        const int tj = rv.tix(idx[j]);
+                        const int tmaxS = (tj == top && cnt == 1) ? second : top;
+                        if (tmaxS > max(tiX, tj)) skip |= 1u << j;
+                    }
+                    passm &= ~skip;
+                    unsurem &= ~skip;
+                    ntests += NT - __popc(skip);
+                }
+                if (VALIDATE && !ill)
+                {  // certified verdicts against double precision, three quarters of the band as margin
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                    {
+                        if ((unsurem >> j) & 1u) continue;
+                        int S[L];
+#pragma unroll
+                        for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
+                        const double r2d = rho2_f64<L>(rv, d, S, idx[j]);
+                        const bool pj = (passm >> j) & 1u;
+                        if (pj ? !(r2d < (double)t2 * (1.0 - 0.25 * (double)kBeta)) : !(r2d > (double)t2 * (1.0 + 0.25 * (double)kBeta))) nbad++;
+                    }
+                }
+                if ((passm | unsurem) != 0u)
+                {  // (static member indices: the set stays in registers)
+#pragma unroll
+                    for (int j = 0; j < NT; j++)
+                    {
+                        if (!(((passm | unsurem) >> j) & 1u)) continue;
+                        int S[L];
+#pragma unroll
+                        for (int a = 0; a < L; a++) S[a] = idx[a < j ? a : a + 1];
+                        const int k2 = idx[j];
+                        const unsigned long long srank = rank_comb<L>(S, d, p.binom);
+                        if ((passm >> j) & 1u)
+                        {
+                            if (rv.separate(k2, srank)) nrem++;
+                        }
+                        else if (rv.live(k2, srank))
+                        {  // uncertain, and not yet decided by a lower set: the exact path
+                            const unsigned long long qi = atomicAdd(&p.cnt->qcount, 1ull);
+                            if (qi < p.qcap)
+                            {
+                                RecheckEntry en;
+                                en.x = rv.X;
+                                en.k2 = k2;
+                                en.rank = srank;
+                                p.queue[qi] = en;
+                            }
                         }
                     }
                 }
             }
-            changed = next_comb_pos<NT>(idx, d);
-            if (changed < 0) break;
         }
     }
     }  // work items

@@ -1,5 +1,5 @@
 """GPU parity of the union-major sweep (csrc/sweep_tmaj.hip: deep levels enumerated by T = S + Y, one inverse per
-l + 1 tests) against the CPU oracle.  By default it runs from level 9; option tmaj_min_level = 2 puts every level
+l + 1 tests) against the CPU oracle.  By default it runs from level 6; option tmaj_min_level = 2 puts every level
 >= 2 of these small cases through it, so adjacency, level counter, separating sets, canonical test counts and pMax
 are checked bit for bit where the oracle finishes in seconds.  `validate` checks every certified verdict of the kernel
 against a double-precision evaluation on the device (cusk_stats.violations must stay 0)."""
@@ -54,10 +54,10 @@ def test_tmaj_ld_block_all_levels(cg, oracle, synth, m, p, maxlevel, validate):
     e.close()
 
 
-@pytest.mark.parametrize("nleaf,nhub,tmin", [(16, 3, 2), (17, 3, 9), (18, 2, 2)])
+@pytest.mark.parametrize("nleaf,nhub,tmin", [(16, 3, 2), (17, 3, 6), (18, 2, 2)])
 def test_tmaj_deepest_levels(cg, oracle, synth, nleaf, nhub, tmin):
     """hubs keep their degree to the end: levels up to 14 through the union-major kernel (from level 2, and from the
-    default level 9 with the set-major kernels below it), validated against double precision on the device"""
+    default level 6 with the set-major kernels below it), validated against double precision on the device"""
     Cm = synth.hub_corr(nleaf, nhub, seed=5)
     Th = cg.threshold_array(20000, 0.01)
     e = cg.Engine(0)
