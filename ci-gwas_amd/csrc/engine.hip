@@ -249,6 +249,16 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.cls = c;
             sp.chunk = (c == 0) ? pl.chunk0 : chunk;
             sp.item_cap = item_cap;
+            sp.grid_cap = item_cap;
+            if (l >= 2 && !pl.use_pair && !pl.tmaj)
+            {
+                // small blocks: no more workgroups than the class can have items -- at most n rows of at most dmax neighbours
+                // with ceil(C(dmax, l) / chunk) items each (the bound of the degrees the host has seen, the class capacity)
+                const int dmax = std::min(pl.maxdeg_bound, kClassCap[c]);
+                const unsigned long long sets = binom_sat(dmax, l);
+                const unsigned long long per_row = sets / sp.chunk + 1ull;
+                if (per_row < (1ull << 40)) sp.grid_cap = std::min<long long>(item_cap, (long long)(per_row * (unsigned long long)n));
+            }
             sp.validate = e->opt_validate;
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.pair_lds, cs));
@@ -553,6 +563,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.cap = 0;
             sp.cls = 0;
             sp.item_cap = item_cap;
+            sp.grid_cap = item_cap;
             sp.cnt = dcnt + l;
             sp.slots = dslots + (size_t)l * kCounterSlots * 4;
             if (a.mode == 0)

@@ -76,6 +76,7 @@ struct SweepParams
     int cap;  // class capacity (LDS carve), ignored when !STAGED
     int cls;  // degree class of this launch: its work-item count is cnt->class_items[cls] (read on the device)
     long long item_cap;         // capacity of the class's work-item buffer
+    long long grid_cap;         // host-side upper bound of the class's work items (<= item_cap): workgroups of the persistent launch
     LevelCounters *cnt;         // this level's counters
     unsigned long long *slots;  // this level's kCounterSlots x 4 spread counters: tests, subsets, removed, violations
     RecheckEntry *queue;

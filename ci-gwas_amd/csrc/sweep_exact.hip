@@ -105,14 +105,14 @@ static hipError_t launch_exact_L(const SweepParams &p, int cls, hipStream_t st)
             if (e != hipSuccess) return e;
         }
         const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, lds),
-                                                            std::max<long long>(p.item_cap, 1));
+                                                            std::max<long long>(p.grid_cap, 1));
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), lds, st, p);
     }
     else
     {
         auto kfn = sweep_kernel<L, MODE, HET, false>;
         const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), kThreads, 16),
-                                                            std::max<long long>(p.item_cap, 1));
+                                                            std::max<long long>(p.grid_cap, 1));
         hipLaunchKernelGGL(kfn, dim3(grid), dim3(kThreads), 16, st, p);
     }
     return hipGetLastError();

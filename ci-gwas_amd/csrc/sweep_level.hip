@@ -840,7 +840,7 @@ unsigned persistent_grid(const void *kernel, int threads, size_t lds)
 hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st)
 {
     const void *kf = mode == 0 ? reinterpret_cast<const void *>(level1_pair_kernel<0>) : reinterpret_cast<const void *>(level1_pair_kernel<1>);
-    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(kf, kThreads, lds), std::max<long long>(p.item_cap, 1));
+    const unsigned grid = (unsigned)std::min<long long>(persistent_grid(kf, kThreads, lds), std::max<long long>(p.grid_cap, 1));
     if (mode == 0)
         hipLaunchKernelGGL(level1_pair_kernel<0>, dim3(grid), dim3(kThreads), lds, st, p);
     else

@@ -401,7 +401,7 @@ static hipError_t launch_vec_LT(const SweepParams &p, int cls, hipStream_t st)
         if (e != hipSuccess) return e;
     }
     const unsigned grid = (unsigned)std::min<long long>(persistent_grid(reinterpret_cast<const void *>(kfn), THREADS, lds),
-                                                        std::max<long long>(p.item_cap, 1));
+                                                        std::max<long long>(p.grid_cap, 1));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(THREADS), lds, st, p);
     return hipGetLastError();
 }

@@ -242,7 +242,10 @@ def main(argv=None):
     t0 = time.perf_counter()
     bs = BlockSet(args.phen, args.bfiles, args.blocks, args.alpha, args.max_level, args.max_level_two, args.depth)
     t_open = time.perf_counter() - t0
-    allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage)
+    # no per-level HIP events: nothing here reads the per-level kernel times, and every event costs the launch-bound
+    # small blocks a few microseconds of device time
+    allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage,
+                                 options={"timing": 0})
     dt = time.perf_counter() - t0
     tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
     print(f"[rank {rank}/{world}] gpu {device}: {len(stats)} blocks ({sum(1 for s in stats.values() if s.skipped)} skipped), "

@@ -26,4 +26,6 @@ for rep in range(1):
     print(f"run {rep}: rc={r.returncode} wall {dt:.3f} s")
     print("\n".join(l for l in r.stdout.splitlines() if "[t]" in l or "level" in l.lower() or "Retained" in l)[:3000])
     if r.returncode: print(r.stderr[-2000:])
-print(sorted((f, os.path.getsize(os.path.join(out, f))) for f in os.listdir(out)))
+import hashlib
+print(sorted((f, os.path.getsize(os.path.join(out, f)), hashlib.sha256(open(os.path.join(out, f), "rb").read()).hexdigest()[:16])
+             for f in os.listdir(out)))
