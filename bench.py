@@ -14,8 +14,9 @@ N > 1 (torchrun, one rank per GPU): BASELINE.json config 4, the whole-chromosome
 (200 blocks x ~500 SNPs x 20 traits on 8 GPUs; weak scaling), written as a PLINK file set, every block through the
 product's block driver (ci-gwas_amd/run_blocks.py: `cusk_blockset_*`, longest-processing-time assignment, the
 pipeline of `mps cusk` per block: correlation build -> stage one -> prune -> stage two -> reduction; .bed staged in
-HBM once per GPU), no collective in the data path, ONE gather of the per-block results to rank 0 (RCCL), which
-writes the per-block files.  One step = one pass of the job over the whole chromosome.
+HBM once per GPU), no collective in the data path.  Files: by default every rank writes the files of its own blocks
+(--writer local: what the reference's one-process-per-block runs do; only a barrier ends the pass); --writer rank0
+gathers the per-block results to rank 0 (ONE exchange over RCCL), which writes every file.  One step = one pass of the job over the whole chromosome.
 
 Prints ONE JSON line on rank 0.
 """
@@ -182,14 +183,14 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
 
     def one_pass(k, timing=0):
         out = None
-        if rank == 0:
+        if rank == 0 or args.writer == "local":
             out = os.path.join(workdir, f"out{k}")
             os.makedirs(out, exist_ok=True)
             outdirs.append(out)
         # timed passes run without per-level HIP events (a dozen per engine run, a few microseconds of device time each:
         # ~6 % of these launch-bound blocks); the per-level kernel times of the roofline come from one untimed detail pass
         return rb.run_job(bs, out, device, inflight=args.inflight, schedule=args.schedule, collective_device=cdev,
-                          options={"timing": timing})
+                          options={"timing": timing}, writer=args.writer)
 
     for k in range(warmup):
         one_pass(-1 - k)
@@ -228,6 +229,10 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
                 lv_sub[l] += st.subsets[l]
         nvar = max(nvar, int(s.markers) + p)
     nwritten = len(allr) if allr is not None else 0
+    if args.writer == "local" and dist is not None:
+        t = torch.tensor([float(nwritten)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        nwritten = int(t[0].item())
     res = {
         "blocks": len(sizes), "markers": int(sum(sizes)), "block_markers_min_mean_max": [int(min(sizes)), float(np.mean(sizes)), int(max(sizes))],
         "blocks_written": nwritten, "passes": steps, "ms_per_pass": dt / steps * 1e3, "blocks_per_sec": len(sizes) * steps / dt,
@@ -235,7 +240,8 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
         "executed_ci_tests_per_sec": tests / dt,
         "rank0_phase_ms_per_pass": {k[3:]: v / steps for k, v in agg.items()},
         "schedule": args.schedule, "inflight": args.inflight, "max_level": args.max_level, "max_level_two": args.max_level_two,
-        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); per-block files written by rank 0 inside the timed region",
+        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); per-block files written inside the timed region",
+        "writer": args.writer,
         "generate_s": t_gen,
     }
     bs.close()
@@ -259,6 +265,9 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=25, help="chromosome workload: LD blocks per GPU (config C4: 200 on 8 GPUs)")
     ap.add_argument("--inflight", type=int, default=1, help="chromosome workload: blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
+    ap.add_argument("--writer", choices=["local", "rank0"], default="local",
+                    help="chromosome workload: local = every rank writes the files of its own blocks (no exchange, as the "
+                         "reference's one process per block); rank0 = one gather of all results, rank 0 writes every file")
     ap.add_argument("--alpha", type=float, default=1e-4)
     ap.add_argument("--engine", choices=["cusk", "cuskss"], default="cusk",
                     help="block workload: cusk = Skeleton engine (sepsets + pMax); cuskss = hetcor engine with uniform ESS")
@@ -308,7 +317,8 @@ def main():
                                 f"({args.blocks_per_gpu} per GPU, {res['markers']} SNPs, sizes {res['block_markers_min_mean_max']}) x "
                                 f"{args.traits} traits, N={args.individuals}, alpha={args.alpha:g}, max level {args.max_level}, "
                                 f"max level two {args.max_level_two}, depth 1; one step = one pass over the chromosome "
-                                f"(.bed -> correlations -> stage one -> prune -> stage two -> reduction -> gather -> files)",
+                                f"(.bed -> correlations -> stage one -> prune -> stage two -> reduction -> "
+                                f"{'files written by the owning rank' if args.writer == 'local' else 'gather -> files written by rank 0'})",
                     "blocks_per_step": res["blocks"], "engine": "cusk", "parallelism": f"block-sharded x{world}, {args.schedule}",
                 },
                 "value_counts": "canonical CI tests of both stages (cusk_stats.canonical_tests: the sequential schedule, device counter); "

@@ -175,9 +175,14 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
 
 def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: str = "lpt", collective_device=None,
             options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block",
-            stage: bool = True):
+            stage: bool = True, writer: str = "rank0"):
     """One rank's part of the job (call on every rank of an initialised process group, or without one for a
-    single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment)."""
+    single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment).
+
+    writer = "rank0": the per-block results are gathered to rank 0 (one exchange at the end of the job), which writes
+    every file.  writer = "local": every rank writes the files of its own blocks into `outdir` (a directory all ranks
+    of the node see) -- what the reference's one-process-per-block runs do; no exchange at all, only a barrier, and the
+    writing is spread over the ranks instead of serialised on one (returns this rank's results)."""
     import torch.distributed as dist
 
     distributed = dist.is_available() and dist.is_initialized()
@@ -193,6 +198,13 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
         owned = shard.assign_blocks(costs, world)[rank]
         queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
     results, stats = run_rank(bs, queue, device, inflight, options, engine_factory, stage)
+    if writer == "local":
+        if outdir is not None:
+            for r in results:
+                r.write(outdir)
+        if distributed:
+            dist.barrier(group)
+        return results, stats, (owned if owned is not None else sorted(stats))
     if distributed:
         allr = shard.gather_results(results, device=collective_device, group=group)
     else:
@@ -216,6 +228,8 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo: CPU collectives)")
     ap.add_argument("--inflight", type=int, default=1, help="blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
+    ap.add_argument("--writer", choices=["rank0", "local"], default="rank0",
+                    help="rank0: results gathered to rank 0, which writes every file; local: every rank writes the files of its own blocks")
     ap.add_argument("--no-stage", action="store_true", help="do not keep the whole .bed in HBM; every block uploads its slice")
     ap.add_argument("--device", type=int, default=None, help="GPU of this rank (default LOCAL_RANK modulo the device count)")
     args = ap.parse_args(argv)
@@ -245,13 +259,13 @@ def main(argv=None):
     # no per-level HIP events: nothing here reads the per-level kernel times, and every event costs the launch-bound
     # small blocks a few microseconds of device time
     allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage,
-                                 options={"timing": 0})
+                                 options={"timing": 0}, writer=args.writer)
     dt = time.perf_counter() - t0
     tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
     print(f"[rank {rank}/{world}] gpu {device}: {len(stats)} blocks ({sum(1 for s in stats.values() if s.skipped)} skipped), "
           f"{tests:.3e} CI tests, open {t_open:.2f} s, total {dt:.2f} s", flush=True)
-    if rank == 0:
-        print(f"Wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}", flush=True)
+    if rank == 0 or args.writer == "local":
+        print(f"[rank {rank}] wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}", flush=True)
     bs.close()
     if world > 1:
         dist.barrier()

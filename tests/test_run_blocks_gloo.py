@@ -67,16 +67,21 @@ def _worker(rank, world, port, outdir, schedule, q):
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from cigwas_amd import run_blocks as rb
 
+    writer = "local" if schedule.endswith("+local") else "rank0"
+    schedule = schedule.split("+")[0]
     allr, stats, owned = rb.run_job(_OracleBlockSet(), outdir, device=0, inflight=2, schedule=schedule,
-                                    engine_factory=_NoEngine, store_key=f"next_{schedule}")
-    assert (allr is None) == (rank != 0)
+                                    engine_factory=_NoEngine, store_key=f"next_{schedule}_{writer}", writer=writer)
+    if writer == "rank0":
+        assert (allr is None) == (rank != 0)
+    else:  # every rank wrote the files of its own blocks and returns them
+        assert sorted(r.block_index for r in allr) == [b for b in sorted(stats) if b != 3]
     q.put((rank, sorted(stats)))
     dist.barrier()
     dist.destroy_process_group()
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("schedule", ["lpt", "dynamic"])
+@pytest.mark.parametrize("schedule", ["lpt", "dynamic", "lpt+local"])
 def test_two_rank_block_driver_partitions_and_gathers(tmp_path, oracle, synth, schedule):
     import torch.multiprocessing as mp
 
@@ -89,7 +94,7 @@ def test_two_rank_block_driver_partitions_and_gathers(tmp_path, oracle, synth, s
     mp.spawn(_worker, args=(2, _free_port(), str(out), schedule, q), nprocs=2, join=True)
     ran = dict(q.get() for _ in range(2))
     assert sorted(ran[0] + ran[1]) == list(range(NBLOCKS))  # a partition: every block exactly once
-    if schedule == "lpt":
+    if schedule.startswith("lpt"):
         owned = shard.assign_blocks(_OracleBlockSet().costs(), 2)
         assert ran[0] == owned[0] and ran[1] == owned[1]
     stems = sorted({f.rsplit(".", 1)[0] for f in os.listdir(out)})
