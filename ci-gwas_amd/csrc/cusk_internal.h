@@ -130,6 +130,7 @@ struct cusk_engine
     int opt_tmaj_min_level = cusk::kTmajMinLevelDefault;  // first level swept by unions T = S + Y (sweep_tmaj.hip); 99 = never
     long long opt_chunk = 2048;
     long long opt_chunk0 = 512;   // conditioning sets per work item of the first degree class
+    long long opt_chunk0_low = 256;  // ... at levels 2-4
     int opt_vec_threads = 64;     // workgroup size of sweep_vec_kernel for the first degree class (64 / 128 / 256)
     long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
     int opt_lookahead = 2;

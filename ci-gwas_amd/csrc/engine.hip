@@ -435,7 +435,10 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     th_l = uniform_ess_threshold(a.Th[0], a.ess_uniform, l);
                 const bool vec0 = (e->opt_fast != 0) && l >= 2 && l < kVecMaxLevel && th_l >= kThMinFilter && !het && e->opt_vec &&
                                   !e->opt_validate && staged_classes > 0;
-                plan[l].chunk0 = vec0 ? chunk0 : chunk;
+                // levels 2-4 of an LD block hold a few thousand sets per row at most: a smaller item (fewer sets per lane in
+                // turn) shortens the serial tail of every item; from level 5 on the staging of an item has to be amortised
+                const unsigned long long c0 = (l <= 4) ? (unsigned long long)std::max<long long>(e->opt_chunk0_low, 64) : chunk0;
+                plan[l].chunk0 = vec0 ? c0 : chunk;
                 // deep levels by unions T = S + Y: single threshold, symmetric matrix (the inverse-based form has no
                 // meaning for the two orientations of an asymmetric input), filter certified for this threshold
                 plan[l].tmaj = (e->opt_fast != 0) && !plan[l].force_exact && l >= std::max(2, e->opt_tmaj_min_level) && l <= kML &&
@@ -905,6 +908,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_tmaj_min_level = (int)value;
     else if (k == "hostprof")
         e->opt_hostprof = (int)value;
+    else if (k == "chunk0_low" && value >= 64)
+        e->opt_chunk0_low = value;
     else if (k == "chunk0" && value >= 64)
         e->opt_chunk0 = value;
     else if (k == "vec_threads" && (value == 64 || value == 128 || value == 256))

@@ -477,8 +477,8 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
                                                   : (L == 1 ? (unsigned long long)d : a.binom[(size_t)d * kBinomStride + a.Lsets]);
         if (nc >= (1ull << 62))
             ovf = true;
-        else if (a.shard_world == 1 || row % a.shard_world == a.shard_rank)
-        {  // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow check are global)
+        else
+        {
             cls = 0;
             while (d > kClassCap[cls]) cls++;
             if (cls >= a.staged_classes) cls = kNumClasses - 1;
@@ -493,10 +493,25 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
                     const unsigned long long per = (unsigned long long)kThreads * tmaj_prefixes_per_lane(d, s, ch);
                     tot += (long long)((nP + per - 1ull) / per);
                 }
-                nchunks = (int)min(tot, (long long)0x7fffffff);
+                if (tot > (long long)0x7fffffff)
+                    ovf = true;  // more work items than a row may have: reported like a binomial overflow
+                else
+                    nchunks = (int)tot;
             }
             else
-                nchunks = (int)((nc + ch - 1) / ch);
+            {
+                const unsigned long long units = (nc + ch - 1) / ch;
+                if (units > 0x7fffffffull)
+                    ovf = true;
+                else
+                    nchunks = (int)units;
+            }
+            // row-sharded runs: only the owner of a row enumerates it (offsets, totals and the overflow checks are global)
+            if (ovf || !(a.shard_world == 1 || row % a.shard_world == a.shard_rank))
+            {
+                cls = -1;
+                nchunks = 0;
+            }
         }
     }
     const bool wave_ovf = __ballot(ovf) != 0ull;

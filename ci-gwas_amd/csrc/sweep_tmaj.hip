@@ -87,6 +87,8 @@ __device__ __noinline__ double rho2_f64(const RV &rv, int d, const int *S, int k
 //
 // Register budget: the inverse of C[Q, Q] is (l - 1) l / 2 registers; four waves per SIMD up to level 7, three up to
 // level 10, two beyond (at three, levels 11 and 12 spilled 60 - 85 values into the loop and ran slower than level 13).
+// Occupancy beats spills here: two waves with 20-60 spilled values (a dozen scratch accesses per union in the hot loop)
+// ran 18.5 / 45.6 / 585 / 1,310 ms at levels 9 / 10 / 13 / 14, one wave less without spills 21.7 / 53.1 / 885 / 1,406.
 template <int L, int MODE, bool STAGED, bool VALIDATE>
 __global__ void __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(L <= 7 ? 4 : (L <= 10 ? 3 : 2))))
 sweep_tmaj_kernel(SweepParams p)
