@@ -347,6 +347,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     // which classes can be staged in LDS in this mode
     int staged_classes = 0;
     while (staged_classes < kNumClasses - 1 && lds_layout(kClassCap[staged_classes], het).total <= kLdsLimit) staged_classes++;
+    if (e->opt_max_staged_classes >= 0) staged_classes = std::min(staged_classes, e->opt_max_staged_classes);  // test hook: 0 = every row through L2
     // The host enqueues levels AHEAD of the device: every kernel of a level checks the level's gate on the device
     // (LevelCounters::active, set by the level's plan), sweeps are persistent launches that read their work-item counts
     // on the device, so no launch needs a number from the host.  The host only follows `lookahead` levels behind (it
@@ -904,6 +905,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_queue_cap = value;
     else if (k == "chunk" && value >= 256)
         e->opt_chunk = value;
+    else if (k == "max_staged_classes")
+        e->opt_max_staged_classes = (int)value;
     else if (k == "tmaj_min_level")
         e->opt_tmaj_min_level = (int)value;
     else if (k == "hostprof")

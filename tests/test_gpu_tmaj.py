@@ -118,3 +118,19 @@ def test_tmaj_recheck_queue_overflow_replans_on_exact_path(cg, oracle):
     st, ref = _check(cg, e, oracle, Cm, Th, 5)
     assert st.exact_fallbacks > 0
     e.close()
+
+
+@pytest.mark.parametrize("tmin", [2, 99])
+def test_unstaged_kernels_every_row_through_l2(cg, oracle, synth, tmin):
+    """max_staged_classes = 0 sends every row to the last degree class, whose kernels read their operands through L2
+    instead of an LDS copy (the path of hubs with more than 191 neighbours): union-major and set-major sweeps"""
+    e = cg.Engine(0)
+    e.set_option("max_staged_classes", 0)
+    e.set_option("tmaj_min_level", tmin)
+    Cm = synth.synth_corr_block(500, 8, N=4096, block_index=77)
+    Th = cg.threshold_array(4096, 1e-4)
+    st, ref = _check(cg, e, oracle, Cm, Th, 5)
+    assert sum(st.removed[2:]) > 0
+    Cm = synth.hub_corr(15, 2, seed=6)
+    _check(cg, e, oracle, Cm, cg.threshold_array(20000, 0.01), 14)
+    e.close()
