@@ -55,11 +55,16 @@ class BlockSet:
         if rc != 0:
             raise RuntimeError(f"cusk_blockset_open: {err.value.decode()}")
         self.h = h
+        self._engines = {}  # device -> engines of this block set (run_rank creates them on first use, close() ends them)
         self.num_blocks = lib().cusk_blockset_num_blocks(h)
         self.num_samples = int(lib().cusk_blockset_num_samples(h))
         self.num_phen = lib().cusk_blockset_num_phen(h)
 
     def close(self):
+        for engines in getattr(self, "_engines", {}).values():
+            for e in engines:
+                e.close()
+        self._engines = {}
         if self.h:
             lib().cusk_blockset_close(self.h)
             self.h = None
@@ -135,7 +140,16 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
     -> (results sorted by block index, {block index: CuskBlockStats}).  `engine_factory` exists for the CPU tests of
     the scheduling / gather logic (a stand-in block set that needs no device); the product always runs on Engine."""
     inflight = max(1, int(inflight))
-    engines = [engine_factory() if engine_factory else Engine(device) for _ in range(inflight)]
+    # engines live as long as the block set (a job that runs several passes, or a service, creates them once: creating
+    # and destroying an engine costs ~10 ms -- streams, events, pinned mirrors, and the device buffers of the first blocks)
+    cache = getattr(bs, "_engines", None) if engine_factory is None else None
+    if cache is not None:
+        engines = cache.setdefault(device, [])
+        while len(engines) < inflight:
+            engines.append(Engine(device))
+        engines = engines[:inflight]
+    else:
+        engines = [engine_factory() if engine_factory else Engine(device) for _ in range(inflight)]
     for e in engines:
         for k, v in (options or {}).items():
             e.set_option(k, int(v))
@@ -166,8 +180,9 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
             t.start()
         for t in threads:
             t.join()
-    for e in engines:
-        e.close()
+    if cache is None:
+        for e in engines:
+            e.close()
     if errors:
         raise errors[0]
     return sorted(results, key=lambda r: r.block_index), stats
