@@ -1259,14 +1259,21 @@ struct RowsStep2
     rows_f2 c;
 };
 
-template <int MODE, bool VALIDATE>
-__global__ void __launch_bounds__(kRowsThreads) level1_rows2_kernel(SweepParams p, RowsParams rp)
+// LDSROW: the columns [ya, n) of the workgroup's row of C are staged in LDS once (coalesced 16-byte loads) and the
+// C[ya, yb] gathers of stage B become LDS reads: with the gathers going through L1/L2 the rows of all resident workgroups
+// (40 KB each at n = 10,020, five per CU) evict each other and the per-edge streams -- 2.3 GB of L2 fills per launch for
+// a 401 MB matrix, which is what bounds the kernel once the instruction count is down (37 % vector issue).  THREADS grows
+// with n so that the CU keeps its waves when fewer rows fit into its 160 KB (launch_level1_rows).
+template <int MODE, bool VALIDATE, int THREADS, bool LDSROW>
+__global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, RowsParams rp)
 {
+    constexpr int kRowsThreads = THREADS, kRowsChunk = THREADS;
     __shared__ int4 s_seg[kRowsChunk];  // {slot of (X, a), a, C[X, row] bits, X}
     __shared__ int s_dx[kRowsChunk];    // degree of X
     __shared__ int s_pre[kRowsChunk + 1];
     __shared__ int s_wtot[2][kRowsThreads / 64];
     __shared__ unsigned long long s_cnt[4];
+    extern __shared__ __attribute__((aligned(16))) float s_row[];  // LDSROW: s_row[col + sh] = C[ya, col], col >= ya
     const int n = p.n;
     const int ya = blockIdx.x;
     if (!p.cnt->active) return;
@@ -1285,6 +1292,36 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows2_kernel(SweepParams 
         mra = rp.rv[m.z + m.y];  // C[X, row]
     }
     const float *crow = p.C + (size_t)ya * n;
+    [[maybe_unused]] int sh = 0;
+    if constexpr (LDSROW)
+    {
+        // LDS index = column + sh with sh = (element offset of the row) mod 4: 16-byte aligned global loads land on
+        // 16-byte aligned LDS addresses whatever n is.  Only columns >= ya are ever asked for (yb follows ya in an
+        // ascending list; idle lanes ask for ya itself).  The rounded-down head and rounded-up tail read at most three
+        // elements of the neighbouring rows (ya >= 1 whenever the head reaches back, ya <= n - 2 always).
+        const size_t g0 = (size_t)ya * n;
+        sh = (int)(g0 & 3);
+        const float *gbase = p.C + (g0 - sh);  // 16-byte aligned (p.C is: checked by the launcher)
+        const int i_end = n + sh;
+        constexpr int kU = 4;
+        for (int i = ((ya + sh) & ~3) + tid * 4; i < i_end; i += THREADS * 4 * kU)
+        {
+            float4 v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; u++)
+            {
+                const int iu = i + u * THREADS * 4;
+                if (iu < i_end) v[u] = *reinterpret_cast<const float4 *>(gbase + iu);
+            }
+#pragma unroll
+            for (int u = 0; u < kU; u++)
+            {
+                const int iu = i + u * THREADS * 4;
+                if (iu < i_end) *reinterpret_cast<float4 *>(s_row + iu) = v[u];
+            }
+        }
+        // visible to every wave after the first barrier of the staging round below
+    }
     [[maybe_unused]] int tiA = 0;
     if constexpr (MODE == 1) tiA = p.time_index[ya];
     const bool use_filter = rp.use_filter != 0;
@@ -1382,8 +1419,16 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows2_kernel(SweepParams 
         auto stage_b = [&](RowsStep2 &st) {
             st.yb0 = st.nb.x;
             st.yb1 = st.in1 ? st.nb.y : st.nb.x;  // the entry behind an odd segment belongs to another list
-            st.c.x = ld32<float>(crow, (unsigned)st.yb0);
-            st.c.y = ld32<float>(crow, (unsigned)st.yb1);
+            if constexpr (LDSROW)
+            {
+                st.c.x = s_row[st.yb0 + sh];
+                st.c.y = s_row[st.yb1 + sh];
+            }
+            else
+            {
+                st.c.x = ld32<float>(crow, (unsigned)st.yb0);
+                st.c.y = ld32<float>(crow, (unsigned)st.yb1);
+            }
         };
         auto stage_c = [&](const RowsStep2 &cur) {
             const int a = cur.a, b = cur.b;
@@ -1637,34 +1682,84 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     const bool two = !(exp & 1) && !(exp & 2);  // two list positions per lane (default); bit 1: the one-position form
+    // Row of C in LDS (4 (n + 8) bytes per workgroup).  The workgroup size grows with n so that a CU keeps its waves
+    // while fewer rows fit into its 160 KB: of 256 / 512 / 1024 threads the size that puts most waves on a CU
+    // (at most 20: 93 VGPRs), the smaller one on a tie; a row that does not fit at all (n > ~36,000) or a matrix
+    // that is not 16-byte aligned is gathered through L1/L2.  exp bit 32 forces the gather form, bits 64 / 128 / 256
+    // force 512 / 1024 / 256 threads.
+    const size_t row_lds = sizeof(float) * ((size_t)n + 8);
+    constexpr size_t kLdsCu = 160 * 1024;
+    int threads = 0;
+    if (two && !(exp & 32) && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)
+    {
+        int best_waves = 0;
+        for (int t : {256, 512, 1024})  // (384 threads, six waves per row, measured 0.373 ms against 0.313 for 512)
+        {
+            const size_t fixed = sizeof(int4) * t + sizeof(int) * (2 * t + 1) + sizeof(int) * 2 * (t / 64) + 64;
+            const int wgs = std::min((int)(kLdsCu / (row_lds + fixed)), 20 / (t / 64));
+            const int waves = wgs * (t / 64);
+            const bool forced = ((exp & 64) && t == 512) || ((exp & 128) && t == 1024) || ((exp & 256) && t == 256);
+            if (wgs > 0 && (waves > best_waves || forced))
+            {
+                best_waves = forced ? 1000 : waves;
+                threads = t;
+            }
+        }
+    }
+#define CUSK_ROWS2_T(M, V, T)                                                                                     \
+    do                                                                                                            \
+    {                                                                                                             \
+        static size_t have = 0;                                                                                   \
+        if (row_lds > have)                                                                                       \
+        {                                                                                                         \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(level1_rows2_kernel<M, V, T, true>),         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)row_lds);                  \
+            have = row_lds;                                                                                       \
+        }                                                                                                         \
+        hipLaunchKernelGGL((level1_rows2_kernel<M, V, T, true>), grid, dim3(T), row_lds, st, p, rp);              \
+    } while (0)
+#define CUSK_ROWS2(M, V)                                                                                          \
+    do                                                                                                            \
+    {                                                                                                             \
+        if (threads == 256)                                                                                       \
+            CUSK_ROWS2_T(M, V, 256);                                                                              \
+        else if (threads == 512)                                                                                  \
+            CUSK_ROWS2_T(M, V, 512);                                                                              \
+        else if (threads == 1024)                                                                                 \
+            CUSK_ROWS2_T(M, V, 1024);                                                                             \
+        else                                                                                                      \
+            hipLaunchKernelGGL((level1_rows2_kernel<M, V, 256, false>), grid, dim3(256), 0, st, p, rp);           \
+    } while (0)
     if (mode == 0 && !validate)
     {
         if (two)
-            hipLaunchKernelGGL((level1_rows2_kernel<0, false>), grid, blk, 0, st, p, rp);
+            CUSK_ROWS2(0, false);
         else
             hipLaunchKernelGGL((level1_rows_kernel<0, false>), grid, blk, 0, st, p, rp);
     }
     else if (mode == 0)
     {
         if (two)
-            hipLaunchKernelGGL((level1_rows2_kernel<0, true>), grid, blk, 0, st, p, rp);
+            CUSK_ROWS2(0, true);
         else
             hipLaunchKernelGGL((level1_rows_kernel<0, true>), grid, blk, 0, st, p, rp);
     }
     else if (!validate)
     {
         if (two)
-            hipLaunchKernelGGL((level1_rows2_kernel<1, false>), grid, blk, 0, st, p, rp);
+            CUSK_ROWS2(1, false);
         else
             hipLaunchKernelGGL((level1_rows_kernel<1, false>), grid, blk, 0, st, p, rp);
     }
     else
     {
         if (two)
-            hipLaunchKernelGGL((level1_rows2_kernel<1, true>), grid, blk, 0, st, p, rp);
+            CUSK_ROWS2(1, true);
         else
             hipLaunchKernelGGL((level1_rows_kernel<1, true>), grid, blk, 0, st, p, rp);
     }
+#undef CUSK_ROWS2
+#undef CUSK_ROWS2_T
     if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode != 0 && !defer_apply)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
