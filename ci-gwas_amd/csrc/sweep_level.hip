@@ -1683,9 +1683,9 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     const bool two = !(exp & 1) && !(exp & 2);  // two list positions per lane (default); bit 1: the one-position form
     // Row of C in LDS (4 (n + 8) bytes per workgroup).  The workgroup size grows with n so that a CU keeps its waves
-    // while fewer rows fit into its 160 KB: of 256 / 512 / 1024 threads the size that puts most waves on a CU
-    // (at most 20: 93 VGPRs), the smaller one on a tie; a row that does not fit at all (n > ~36,000) or a matrix
-    // that is not 16-byte aligned is gathered through L1/L2.  exp bit 32 forces the gather form, bits 64 / 128 / 256
+    // while fewer rows fit into its 160 KB: of 256 / 512 threads the size that puts most waves on a CU (at most 20:
+    // 93 VGPRs), the smaller one on a tie; when two rows do not fit (n > ~16,000) or the matrix is not 16-byte aligned
+    // the row is gathered through L1/L2.  exp bit 32 forces the gather form, bits 64 / 128 / 256
     // force 512 / 1024 / 256 threads.
     const size_t row_lds = sizeof(float) * ((size_t)n + 8);
     constexpr size_t kLdsCu = 160 * 1024;
@@ -1693,13 +1693,16 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (two && !(exp & 32) && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)
     {
         int best_waves = 0;
-        for (int t : {256, 512, 1024})  // (384 threads, six waves per row, measured 0.373 ms against 0.313 for 512)
+        // measured at n = 10,020 (gather form 0.336 ms): 512 threads 0.313, 256 threads 0.316, 384 threads (six waves per
+        // row) 0.373, 1,024 threads (one row per CU) 0.408 -- so the LDS form is only taken while two rows fit (n <= ~16,000)
+        for (int t : {256, 512, 1024})
         {
             const size_t fixed = sizeof(int4) * t + sizeof(int) * (2 * t + 1) + sizeof(int) * 2 * (t / 64) + 64;
             const int wgs = std::min((int)(kLdsCu / (row_lds + fixed)), 20 / (t / 64));
             const int waves = wgs * (t / 64);
             const bool forced = ((exp & 64) && t == 512) || ((exp & 128) && t == 1024) || ((exp & 256) && t == 256);
-            if (wgs > 0 && (waves > best_waves || forced))
+            if (t == 1024 && !forced) continue;
+            if (wgs >= (forced ? 1 : 2) && (waves > best_waves || forced))
             {
                 best_waves = forced ? 1000 : waves;
                 threads = t;
