@@ -82,6 +82,8 @@ SYMBOLS = {
     "cusk_result_sepset_dense": (_i, [_vp, _vp]),
     "cusk_result_sepsets": (_ll, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cusk_corr_build": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "cusk_corr_build_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
+    "cusk_corr_build_end": (_i, [_vp, _vp]),
     "cusk_corr_timing": (None, [_vp, _vp]),
     "cusk_corr_banded": (_i, [_vp, _vp, _sz, _sz, _sz, _vp, _vp]),
     "cusk_hanning_smooth": (_i, [_vp, _vp, _sz, _vp, _i, _vp]),
@@ -97,6 +99,7 @@ SYMBOLS = {
     "cusk_blockset_block_stem": (_i, [_vp, _i, C.c_char_p, _sz]),
     "cusk_blockset_stage": (_i, [_vp, _vp]),
     "cusk_blockset_run_block": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
+    "cusk_blockset_run_block_next": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
     "cusk_blockset_last_error": (C.c_char_p, []),
     "cusk_block_result_dims": (None, [_vp, C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
     "cusk_block_result_stem": (C.c_char_p, [_vp]),

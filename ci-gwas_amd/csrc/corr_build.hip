@@ -15,6 +15,7 @@
 // .bed 2-bit codes, low bits first: 00 -> 2, 01 -> missing, 10 -> 1, 11 -> 0.
 #include <type_traits>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 #include "cusk_internal.h"
@@ -946,19 +947,24 @@ static bool is_device_pointer(const void *p)
     return attr.type == hipMemoryTypeDevice;
 }
 
+// `ahead`: the build of the NEXT block, enqueued on the engine's third stream while the current block is swept
+// (cusk_corr_build_begin): device-resident inputs only, no events, no synchronisation; the marker x trait correlations
+// land in `mxp_host` (pinned) when the stream gets there.
 int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N, size_t p,
                     const float *mean, const float *std, float *C_dev, float *mxp_host, float *mxm_tri_host,
-                    float *pxp_tri_host)
+                    float *pxp_tri_host, bool ahead)
 {
     if (!e || !bed || !phen || !mean || !std || m == 0 || N == 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
     CUSK_HIP(e, hipSetDevice(e->device));
-    hipStream_t s = e->stream;
+    hipStream_t s = ahead ? e->stream3 : e->stream;
+    if (ahead && !(is_device_pointer(bed) && is_device_pointer(phen) && is_device_pointer(mean) && is_device_pointer(std)))
+        return fail(e, CUSK_ERR_ARG, "cusk_corr_build_begin needs device-resident inputs");
     const size_t clb = (N + 3) / 4, w64 = (N + 63) / 64, n = m + p;
     // Inputs that already live in HBM (a whole .bed staged once per GPU by the block driver, cusk_blockset_stage)
     // are used where they are; host inputs are copied to engine scratch first.
     const unsigned char *bed_d = nullptr;
     const float *phen_d = nullptr, *mean_d = nullptr, *std_d = nullptr;
-    CUSK_HIP(e, hipEventRecord(e->ev_corr[0], s));
+    if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[0], s));
     if (is_device_pointer(bed))
         bed_d = bed;
     else
@@ -997,14 +1003,14 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         CUSK_HIP(e, e->mxp_dev.ensure(sizeof(float) * m * p));
         mxp_d = e->mxp_dev.as<float>();
     }
-    CUSK_HIP(e, hipEventRecord(e->ev_corr[1], s));
+    if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[1], s));
     if (C_dev && e->opt_corr_popcount)
     {
         // cross-check path: bit planes + AND/popcount (no matrix cores)
         CUSK_HIP(e, e->planes.ensure(sizeof(unsigned long long) * 3 * m * w64));
         hipLaunchKernelGGL(bed_to_bitplanes_kernel, dim3((unsigned)((m * w64 + 255) / 256)), dim3(256), 0, s,
                            bed_d, e->planes.as<unsigned long long>(), m, N, clb, w64);
-        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
+        if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kTile - 1) / kTile);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
         hipLaunchKernelGGL(mxm_popcount_kernel, dim3((unsigned)nt), dim3(256), 0, s, e->planes.as<unsigned long long>(),
@@ -1013,7 +1019,7 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     }
     else if (C_dev)
     {
-        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
+        if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
         const int tiles = (int)((m + kMT - 1) / kMT);
         const long long nt = (long long)tiles * (tiles + 1) / 2;
         const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_d) & 15u) == 0);
@@ -1030,9 +1036,9 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     }
     else
     {
-        CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
+        if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
     }
-    CUSK_HIP(e, hipEventRecord(e->ev_corr[3], s));
+    if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[3], s));
     for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
     {
         const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
@@ -1058,8 +1064,9 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, phen_d, C_dev, m,
                            N, p, n);
     CUSK_HIP(e, hipGetLastError());
-    CUSK_HIP(e, hipEventRecord(e->ev_corr[4], s));
+    if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[4], s));
     if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(mxp_host, mxp_d, sizeof(float) * m * p, hipMemcpyDeviceToHost, s));
+    if (ahead) return CUSK_OK;  // cusk_corr_build_end waits for the stream
     if (C_dev && (mxm_tri_host || pxp_tri_host))
     {
         DevBuf tri;
@@ -1200,6 +1207,38 @@ extern "C" int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const f
                                const float *mean, const float *std, float *C_dev, float *mxp_host)
 {
     return corr_build_impl(e, bed, phen, m, N, p, mean, std, C_dev, mxp_host, nullptr, nullptr);
+}
+
+// The build of the next block while the current one is swept: begin enqueues everything on the engine's third stream and
+// returns; end waits for it and hands over the marker x trait correlations.  One build in flight per engine.
+extern "C" int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N,
+                                     size_t p, const float *mean_dev, const float *std_dev, float *C_dev)
+{
+    if (!e || !C_dev || p == 0) return e ? fail(e, CUSK_ERR_ARG, "bad arguments") : CUSK_ERR_ARG;
+    if (e->mxp_pending) return fail(e, CUSK_ERR_ARG, "a correlation build is already in flight");
+    if (m * p > e->mxp_pinned_cap)
+    {
+        if (e->mxp_pinned) (void)hipHostFree(e->mxp_pinned);
+        e->mxp_pinned = nullptr;
+        e->mxp_pinned_cap = 0;
+        CUSK_HIP(e, hipHostMalloc(reinterpret_cast<void **>(&e->mxp_pinned), sizeof(float) * (m * p + m * p / 4 + 64)));
+        e->mxp_pinned_cap = m * p + m * p / 4 + 64;
+    }
+    const int rc = corr_build_impl(e, bed_dev, phen_dev, m, N, p, mean_dev, std_dev, C_dev, e->mxp_pinned, nullptr, nullptr, true);
+    if (rc == CUSK_OK) e->mxp_pending = m * p;
+    return rc;
+}
+
+extern "C" int cusk_corr_build_end(cusk_engine *e, float *mxp_host)
+{
+    if (!e) return CUSK_ERR_ARG;
+    if (!e->mxp_pending) return fail(e, CUSK_ERR_ARG, "no correlation build in flight");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t count = e->mxp_pending;
+    e->mxp_pending = 0;
+    CUSK_HIP(e, hipStreamSynchronize(e->stream3));
+    if (mxp_host) std::memcpy(mxp_host, e->mxp_pinned, sizeof(float) * count);
+    return CUSK_OK;
 }
 
 extern "C" void cusk_corr_timing(const cusk_engine *e, float *ms4)

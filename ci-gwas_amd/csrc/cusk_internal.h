@@ -68,6 +68,9 @@ struct cusk_engine
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;  // auxiliary stream: independent degree classes, off-critical-path kernels
+    hipStream_t stream3 = nullptr;  // correlation build of the NEXT block while this one is swept (cusk_corr_build_begin / _end)
+    float *mxp_pinned = nullptr;    // pinned landing buffer of the prefetched marker x trait correlations
+    size_t mxp_pinned_cap = 0, mxp_pending = 0;  // floats; mxp_pending > 0: a build is in flight on stream3
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_z = nullptr;
     bool own_stream = false;
     std::string err;
@@ -180,7 +183,7 @@ float hetcor_threshold_host(float alpha);
 // corr_build.hip
 int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m, size_t N,
                     size_t p, const float *mean, const float *std, float *C_dev, float *mxp_host,
-                    float *mxm_tri_host, float *pxp_tri_host);
+                    float *mxm_tri_host, float *pxp_tri_host, bool ahead = false);
 
 // reference-named correlation entry points (corr_build.hip); C linkage in compat_api.hip, C++ linkage in compat_cxx.cpp
 void compat_marker_phen_corr_pearson(const unsigned char *marker_vals, const float *phen_vals, const size_t num_markers,

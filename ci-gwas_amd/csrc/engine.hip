@@ -789,6 +789,7 @@ extern "C" int cusk_engine_create(cusk_engine **out, int device, void *stream)
         e->own_stream = ok;
     }
     ok = ok && hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking) == hipSuccess;
+    ok = ok && hipStreamCreateWithFlags(&e->stream3, hipStreamNonBlocking) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&e->ev_z, hipEventDisableTiming) == hipSuccess;
@@ -872,9 +873,12 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
         for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
             if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    if (e->stream3) (void)hipStreamSynchronize(e->stream3);
     for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
+    if (e->stream3) (void)hipStreamDestroy(e->stream3);
+    if (e->mxp_pinned) (void)hipHostFree(e->mxp_pinned);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }

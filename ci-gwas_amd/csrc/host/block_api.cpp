@@ -130,8 +130,19 @@ extern "C" int cusk_blockset_stage(cusk_blockset *bs, cusk_engine *e)
     return CUSK_OK;
 }
 
+extern "C" int cusk_blockset_run_block_next(cusk_blockset *bs, cusk_engine *e, int block_index, int next_index,
+                                            cusk_block_result **out, cusk_block_stats *stats);
+
 extern "C" int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, cusk_block_result **out,
                                        cusk_block_stats *stats)
+{
+    return cusk_blockset_run_block_next(bs, e, block_index, -1, out, stats);
+}
+
+// next_index >= 0: the block this engine runs next -- its correlation matrix is built beside this block's sweeps (staged
+// inputs only; a different block may still be asked for next, the build is then dropped)
+extern "C" int cusk_blockset_run_block_next(cusk_blockset *bs, cusk_engine *e, int block_index, int next_index,
+                                            cusk_block_result **out, cusk_block_stats *stats)
 {
     if (!bs || !e || !out) return CUSK_ERR_ARG;
     *out = nullptr;
@@ -140,7 +151,7 @@ extern "C" int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int bl
     BlockStats st;
     try
     {
-        const bool kept = run_cusk_block(e, bs->in, block_index, scratch, res->r, res->stem, st, nullptr, bs->staged_of(e));
+        const bool kept = run_cusk_block(e, bs->in, block_index, scratch, res->r, res->stem, st, nullptr, bs->staged_of(e), next_index);
         if (stats)
         {
             stats->skipped = st.skipped;

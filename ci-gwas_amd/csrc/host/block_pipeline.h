@@ -325,11 +325,24 @@ struct BlockStats
 struct BlockScratch
 {
     DevMat C, C2;
+    // the NEXT block's correlation matrix, being built on the engine's third stream while this block is swept
+    // (cusk_corr_build_begin / _end): pending >= 0 = its block index, pending_m = its marker count
+    DevMat Cnext;
+    int pending = -1;
+    size_t pending_m = 0;
+    void swap_next()
+    {
+        std::swap(C.p, Cnext.p);
+        std::swap(C.cap, Cnext.cap);
+    }
 };
 
 // cli.cpp:521-677 for blocks[block_index] on the engine's device.  Returns false when the block is skipped.
+// next_index >= 0 (block driver, device-resident inputs): the correlation build of that block is started as soon as this
+// block's own matrix is complete and runs beside this block's sweeps; the call for block next_index then only waits for it.
 inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index, BlockScratch &scr, Reduced &out,
-                           std::string &stem, BlockStats &bs, std::ostream *log, const StagedInputs *staged = nullptr)
+                           std::string &stem, BlockStats &bs, std::ostream *log, const StagedInputs *staged = nullptr,
+                           int next_index = -1)
 {
     using clk = std::chrono::steady_clock;
     auto ms_since = [](clk::time_point &t) {
@@ -383,15 +396,43 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
     bs.ms_inputs = ms_since(t);
 
     const size_t n = m + p;
-    scr.C.reserve(n * n);
     if (log)
     {
         *log << "Checking for significant marker - phen correlations" << std::endl;
         *log << "Computing all correlations" << std::endl;
     }
     std::vector<float> mxp(m * p);
-    if (cusk_corr_build(e, bed, phen, m, N, p, means, stds, scr.C.p, mxp.data()) != CUSK_OK)
-        engine_die("correlation build", e);
+    if (scr.pending == block_index && scr.pending_m == m)
+    {  // built ahead, beside the previous block's sweeps
+        scr.pending = -1;
+        scr.swap_next();
+        if (cusk_corr_build_end(e, mxp.data()) != CUSK_OK) engine_die("correlation build (end)", e);
+    }
+    else
+    {
+        if (scr.pending >= 0)
+        {  // a build for another block is in flight (the caller changed its mind): let it finish, drop it
+            scr.pending = -1;
+            if (cusk_corr_build_end(e, nullptr) != CUSK_OK) engine_die("correlation build (end)", e);
+        }
+        scr.C.reserve(n * n);
+        if (cusk_corr_build(e, bed, phen, m, N, p, means, stds, scr.C.p, mxp.data()) != CUSK_OK)
+            engine_die("correlation build", e);
+    }
+    if (staged && p > 0 && next_index >= 0 && (size_t)next_index < in.blocks.size() && next_index != block_index)
+    {
+        const Block &nb = in.blocks[next_index];
+        const size_t m2 = nb.size(), h0 = in.first_marker(nb), n2 = m2 + p;
+        if (m2 > 0 && 3 + (h0 + m2) * bpc <= in.bed.size)
+        {
+            scr.Cnext.reserve(n2 * n2);
+            if (cusk_corr_build_begin(e, staged->bed + h0 * bpc, staged->phen, m2, N, p, staged->means + h0, staged->stds + h0,
+                                      scr.Cnext.p) != CUSK_OK)
+                engine_die("correlation build (begin)", e);
+            scr.pending = next_index;
+            scr.pending_m = m2;
+        }
+    }
     bs.ms_corr = ms_since(t);
     // cli.cpp:561-576: blocks without any marginally significant marker-trait correlation are skipped
     int num_sig = 0;

@@ -85,11 +85,12 @@ class BlockSet:
     def costs(self) -> list[float]:
         return [shard.predicted_cost(self.markers(i), self.num_samples, self.num_phen) for i in range(self.num_blocks)]
 
-    def run_block(self, eng: Engine, i: int):
-        """-> (shard.BlockResult | None if the block is skipped, CuskBlockStats)"""
+    def run_block(self, eng: Engine, i: int, next_block: int = -1):
+        """-> (shard.BlockResult | None if the block is skipped, CuskBlockStats).  next_block: the block this engine
+        runs next (its correlation matrix is then built beside this block's sweeps), -1 = unknown / none"""
         res = C.c_void_p()
         st = CuskBlockStats()
-        rc = lib().cusk_blockset_run_block(self.h, eng.h, int(i), C.byref(res), C.byref(st))
+        rc = lib().cusk_blockset_run_block_next(self.h, eng.h, int(i), int(next_block), C.byref(res), C.byref(st))
         if rc != 0:
             raise RuntimeError(f"block {i}: {lib().cusk_blockset_last_error().decode()}")
         if not res:
@@ -133,6 +134,13 @@ class _Queue:
                 self.pos += 1
         return self.order[k] if k < len(self.order) else None
 
+    def peek(self):
+        """the block next() would return now, or -1 when that is not known (shared counter, end of the list)"""
+        if self.store is not None:
+            return -1
+        with self.lock:
+            return self.order[self.pos] if self.pos < len(self.order) else -1
+
 
 def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None,
              stage: bool = True):
@@ -152,11 +160,13 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
         engines = [engine_factory() if engine_factory else Engine(device) for _ in range(inflight)]
     for e in engines:
         for k, v in (options or {}).items():
-            e.set_option(k, int(v))
+            if k != "corr_ahead":  # (the driver's own switch: correlation build of the next block beside this block's sweeps)
+                e.set_option(k, int(v))
     if stage and hasattr(bs, "stage"):
         bs.stage(engines[0])  # best effort: without it every block uploads its own slice
     results, stats, errors = [], {}, []
     lock = threading.Lock()
+    ahead = engine_factory is None and stage and int((options or {}).get("corr_ahead", 1)) != 0
 
     def worker(eng):
         try:
@@ -164,7 +174,9 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
                 b = queue.next()
                 if b is None or errors:
                     return
-                br, st = bs.run_block(eng, b)
+                # one engine per rank: the block it takes next is known, and its correlations are built ahead
+                nxt = queue.peek() if (inflight == 1 and ahead) else -1
+                br, st = bs.run_block(eng, b, nxt) if nxt >= 0 else bs.run_block(eng, b)
                 with lock:
                     stats[b] = st
                     if br is not None:

@@ -192,6 +192,12 @@ long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *level, float 
 int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen, size_t m,
                     size_t N, size_t p, const float *mean, const float *std, float *C_dev,
                     float *mxp_host);
+/* The same build for the NEXT block of a job while the current one is swept: begin enqueues it on a stream of its own
+ * (device-resident inputs only: cusk_blockset_stage) and returns at once, end waits for it and copies the marker x trait
+ * correlations out.  One build in flight per engine; the matrix must not be read before end returns. */
+int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N, size_t p,
+                          const float *mean_dev, const float *std_dev, float *C_dev);
+int cusk_corr_build_end(cusk_engine *e, float *mxp_host);
 /* timing of the last cusk_corr_build: [0] decode, [1] count GEMM, [2] mxp/pxp, [3] total (ms) */
 void cusk_corr_timing(const cusk_engine *e, float *ms4);
 
@@ -281,6 +287,10 @@ int cusk_blockset_stage(cusk_blockset *bs, cusk_engine *e);
  * stats may be NULL.  Error text: cusk_blockset_last_error (per calling thread). */
 int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, cusk_block_result **out,
                             cusk_block_stats *stats);
+/* the same, naming the block this engine runs next: its correlation build (cusk_corr_build_begin) runs beside this block's
+ * sweeps when the inputs are staged in HBM; next_index = -1: none */
+int cusk_blockset_run_block_next(cusk_blockset *bs, cusk_engine *e, int block_index, int next_index,
+                                 cusk_block_result **out, cusk_block_stats *stats);
 const char *cusk_blockset_last_error(void);
 /* the reduced result of one block: what ReducedGCS::to_file writes (include/mps/parent_set.h:42-52) */
 void cusk_block_result_dims(const cusk_block_result *r, long long *num_var, long long *num_phen, long long *max_level);

@@ -152,6 +152,39 @@ def test_in_process_driver_with_blocks_in_flight_and_oracle_check(chromosome, tm
     bs.close()
 
 
+@pytest.mark.parametrize("ahead", [1, 0])
+def test_correlation_build_of_the_next_block_runs_beside_the_sweeps(chromosome, tmp_path, ahead):
+    """one engine per rank: the driver names the block the engine takes next and its correlation matrix is built on a
+    third stream while the current block is swept (cusk_corr_build_begin / _end); files as from per-block `mps cusk`.
+    Also: naming one block and then asking for another drops the build that is in flight."""
+    from cigwas_amd import run_blocks as rb
+    from cigwas_amd.skeleton import Engine
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), int(DEPTH))
+    out = tmp_path / "out"
+    out.mkdir()
+    allr, stats, owned = rb.run_job(bs, str(out), device=0, inflight=1, options={"corr_ahead": ahead, "timing": 0})
+    _same_files(str(chromosome["ref"]), str(out))
+    if ahead:
+        e = Engine(0)
+        assert bs.stage(e)
+        a, b, c = chromosome["signal"][0], chromosome["signal"][1], chromosome["signal"][-1]
+        out2 = tmp_path / "out2"
+        out2.mkdir()
+        r1, _ = bs.run_block(e, a, next_block=b)   # builds b ahead ...
+        r3, _ = bs.run_block(e, c, next_block=a)   # ... but c is asked for: b's build is dropped, a is built ahead
+        r2, _ = bs.run_block(e, a)                 # a again: taken from the build in flight
+        r4, _ = bs.run_block(e, b)
+        for r in (r1, r3, r4):
+            r.write(str(out2))
+        ref = {f for f in os.listdir(str(chromosome["ref"]))}
+        for f in os.listdir(str(out2)):
+            assert f in ref and open(os.path.join(str(out2), f), "rb").read() == open(os.path.join(str(chromosome["ref"]), f), "rb").read()
+        assert np.array_equal(r1.adj, r2.adj) and np.array_equal(r1.sep, r2.sep) and np.array_equal(r1.corr, r2.corr)
+        e.close()
+    bs.close()
+
+
 def test_blockset_reports_bad_inputs(tmp_path, chromosome):
     from cigwas_amd import run_blocks as rb
 
