@@ -143,7 +143,7 @@ class _Queue:
 
 
 def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None,
-             stage: bool = True):
+             stage: bool = True, write_dir: str | None = None):
     """Runs blocks from `queue` on GPU `device` with `inflight` engines (one host thread each).
     -> (results sorted by block index, {block index: CuskBlockStats}).  `engine_factory` exists for the CPU tests of
     the scheduling / gather logic (a stand-in block set that needs no device); the product always runs on Engine."""
@@ -166,6 +166,25 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
         bs.stage(engines[0])  # best effort: without it every block uploads its own slice
     results, stats, errors = [], {}, []
     lock = threading.Lock()
+    # write_dir: the files of a block are written by a thread of their own as soon as the block is done, beside the
+    # engine's work on the next block (the engine calls release the interpreter lock)
+    import queue as _q
+
+    wq = _q.Queue() if write_dir is not None else None
+
+    def writer():
+        while True:
+            r = wq.get()
+            if r is None:
+                return
+            try:
+                r.write(write_dir)
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+    wt = threading.Thread(target=writer) if wq is not None else None
+    if wt is not None:
+        wt.start()
     ahead = engine_factory is None and stage and int((options or {}).get("corr_ahead", 1)) != 0
 
     def worker(eng):
@@ -181,6 +200,8 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
                     stats[b] = st
                     if br is not None:
                         results.append(br)
+                        if wq is not None:
+                            wq.put(br)
         except Exception as exc:  # noqa: BLE001 -- re-raised on the calling thread
             errors.append(exc)
 
@@ -192,6 +213,9 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
             t.start()
         for t in threads:
             t.join()
+    if wt is not None:
+        wq.put(None)
+        wt.join()
     if cache is None:
         for e in engines:
             e.close()
@@ -224,11 +248,9 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
     else:
         owned = shard.assign_blocks(costs, world)[rank]
         queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
-    results, stats = run_rank(bs, queue, device, inflight, options, engine_factory, stage)
+    results, stats = run_rank(bs, queue, device, inflight, options, engine_factory, stage,
+                              write_dir=outdir if writer == "local" else None)
     if writer == "local":
-        if outdir is not None:
-            for r in results:
-                r.write(outdir)
         if distributed:
             dist.barrier(group)
         return results, stats, (owned if owned is not None else sorted(stats))
