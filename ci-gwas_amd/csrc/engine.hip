@@ -214,7 +214,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         {
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
                                            e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->opt_timing ? e->ev_main[0] : nullptr,
-                                           e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, e->opt_l1_exp, sharded, s));
+                                           e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, e->opt_l1_exp, sharded,
+                                           a.time_index != nullptr, s));
             rows_timed = true;
             return CUSK_OK;
         }

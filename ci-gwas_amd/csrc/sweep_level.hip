@@ -908,6 +908,7 @@ struct RowsParams
     const int4 *meta;
     unsigned *sel;   // level-1 selection state per CSR slot: lowest passing position (Skeleton) / 0 = edge gone (hetcor)
     int use_filter;  // 0: every test on the exact arithmetic (thresholds too small for the guard band)
+    int has_ti;      // hetcor engine: a time index was given (else every index is 0 and the rule excludes nothing)
     float beta;      // half-width of the level-1 guard band on rho^2 (level1_beta)
     int exp;         // experiment bits: 2 = rows contiguous per XCD, 4 = count the atomics, 8 = non-temporal meta loads
     int shard_rank, shard_world;  // row-sharded runs: this engine streams the rows ya with ya % world == rank
@@ -1121,11 +1122,16 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
                 needA = act;
                 needB = act;
             }
-            else
+            else if (rp.has_ti)
             {
                 const int tiX = p.time_index[cur.X], tiB = p.time_index[yb];
                 needA = act && !(tiB > max(tiX, tiA));
                 needB = act && !(tiA > max(tiX, tiB));
+            }
+            else
+            {
+                needA = act;
+                needB = act;
             }
             const float hc = 1.0f - (c * c);
             const float h00a = 1.0f - (rb * rb), h01a = ra - (rb * c);
@@ -1441,13 +1447,18 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
                 needA0 = needB0 = cur.in0;
                 needA1 = needB1 = cur.in1;
             }
-            else
+            else if (rp.has_ti)
             {
                 const int tiX = p.time_index[cur.X], tiB0 = p.time_index[cur.yb0], tiB1 = p.time_index[cur.yb1];
                 needA0 = cur.in0 && !(tiB0 > max(tiX, tiA));
                 needB0 = cur.in0 && !(tiA > max(tiX, tiB0));
                 needA1 = cur.in1 && !(tiB1 > max(tiX, tiA));
                 needB1 = cur.in1 && !(tiA > max(tiX, tiB1));
+            }
+            else
+            {  // no time index given (all equal): the rule excludes nothing, and its three gathers per lane and step go
+                needA0 = needB0 = cur.in0;
+                needA1 = needB1 = cur.in1;
             }
             // per element exactly the operations of the one-position form: 1 - (c c), ra - (rb c), t2 ((h00) (hc)), ...
             const rows_f2 one = {1.0f, 1.0f}, rav = {ra, ra};
@@ -1664,7 +1675,7 @@ hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, bool c
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, int exp, bool defer_apply, hipStream_t st)
+                              int shard_world, int exp, bool defer_apply, bool has_ti, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -1674,6 +1685,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.meta = static_cast<const int4 *>(meta);
     rp.sel = sel;
     rp.use_filter = use_filter ? 1 : 0;
+    rp.has_ti = has_ti ? 1 : 0;
     rp.beta = (exp & 512) ? kBeta : level1_beta(p.t2);  // bit 512: the wide band of the deeper levels
     rp.exp = exp;
     rp.shard_rank = shard_rank;
