@@ -339,7 +339,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         }
         if (rc != 0) return fail(e, CUSK_ERR_ARG, "row-shard exchange failed at level " + std::to_string(l));
         // hetcor: every engine now drops the edges any engine removed (bitmap rows and degrees, identically everywhere)
-        if (a.mode == 1) CUSK_HIP(e, launch_level1_apply(pl.sp, e->sel.as<unsigned>(), false, s));
+        if (a.mode == 1)
+            CUSK_HIP(e, launch_level1_apply(pl.sp, e->sel.as<unsigned>(), (l == 1 && pl.use_rows) ? e->rpos.p : nullptr, false, s));
         return CUSK_OK;
     };
 

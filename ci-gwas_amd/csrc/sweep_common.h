@@ -296,7 +296,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
                               int shard_world, int exp, bool defer_apply, bool has_ti, hipStream_t st);
 // hetcor mode, row-sharded runs: adjacency bitmap -> per-slot marks (0 gone / all ones alive), and back after the join
 hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStream_t st);
-hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, bool count_removed, hipStream_t st);
+hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, const void *meta, bool count_removed, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);

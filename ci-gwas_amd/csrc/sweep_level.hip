@@ -1179,16 +1179,8 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
                 // hetcor: the edge goes in both directions; both directed slots are marked with plain stores (racing
                 // writers store the same 0) and the bitmap / degrees are updated once afterwards (level1_apply_kernel),
                 // so the sweep carries no returning atomics
-                if (passB)
-                {
-                    rp.sel[cur.ib] = 0u;
-                    rp.sel[p.off[yb] + rp.meta[cur.ib].y] = 0u;
-                }
-                if (headA)
-                {
-                    rp.sel[cur.ia] = 0u;
-                    rp.sel[o0 + rp.meta[cur.ia].y] = 0u;
-                }
+                if (passB) rp.sel[cur.ib] = 0u;
+                if (headA) rp.sel[cur.ia] = 0u;
             }
         };
         // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
@@ -1530,21 +1522,10 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
             {
                 // hetcor: the edge goes in both directions; both directed slots are marked with plain stores (racing
                 // writers store the same 0), bitmap and degrees are updated once afterwards (level1_apply_kernel)
-                if (passB0)
-                {
-                    rp.sel[cur.ib] = 0u;
-                    rp.sel[p.off[cur.yb0] + rp.meta[cur.ib].y] = 0u;
-                }
-                if (passB1)
-                {
-                    rp.sel[cur.ib + 1] = 0u;
-                    rp.sel[p.off[cur.yb1] + rp.meta[cur.ib + 1].y] = 0u;
-                }
-                if (headA)
-                {
-                    rp.sel[cur.ia] = 0u;
-                    rp.sel[o0 + rp.meta[cur.ia].y] = 0u;
-                }
+                // (only the slot of the ordered pair that was tested; level1_apply_kernel removes the edge in both directions)
+                if (passB0) rp.sel[cur.ib] = 0u;
+                if (passB1) rp.sel[cur.ib + 1] = 0u;
+                if (headA) rp.sel[cur.ia] = 0u;
             }
         };
         // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
@@ -1597,9 +1578,12 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
 // hetcor mode, after the sweep: every row drops the neighbours whose slot was marked (the wave owns its bitmap row:
 // word-aggregated plain read-modify-writes as in gather_records), sets its degree, and the removed directed edges
 // are counted
+// meta != nullptr (level 1 behind the row-streaming kernel): a slot is marked by the test of ITS ordered pair only, so the
+// slot of the reverse pair is looked at as well (the edge goes when either direction found a separating variable)
 __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict__ off, const int *__restrict__ nbr,
                                                            const unsigned *__restrict__ sel, unsigned long long *adj, int *deg,
-                                                           int n, int words, unsigned long long *slots, const LevelCounters *cnt)
+                                                           int n, int words, unsigned long long *slots, const LevelCounters *cnt,
+                                                           const int4 *__restrict__ meta)
 {
     __shared__ int s_sum[4];
     if (!cnt->active) return;
@@ -1614,7 +1598,12 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
             const int k = k0 + lane;
             const bool valid = k < d;
             const int Y = valid ? nbr[o0 + k] : 0;
-            const bool gone = valid && (sel[o0 + k] == 0u);
+            bool gone = valid && (sel[o0 + k] == 0u);
+            if (valid && !gone && meta != nullptr)
+            {
+                const int4 m = meta[o0 + k];
+                gone = (sel[m.z + m.y] == 0u);
+            }
             const int w = valid ? (Y >> 6) : -1 - lane;
             unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
 #pragma unroll
@@ -1666,10 +1655,10 @@ hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStre
     return hipGetLastError();
 }
 
-hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, bool count_removed, hipStream_t st)
+hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, const void *meta, bool count_removed, hipStream_t st)
 {
     hipLaunchKernelGGL(level1_apply_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, p.n, p.words,
-                       count_removed ? p.slots : nullptr, p.cnt);
+                       count_removed ? p.slots : nullptr, p.cnt, static_cast<const int4 *>(meta));
     return hipGetLastError();
 }
 
@@ -1778,7 +1767,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode != 0 && !defer_apply)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
-                           p.words, p.slots, p.cnt);
+                           p.words, p.slots, p.cnt, static_cast<const int4 *>(meta));
     return hipGetLastError();
 }
 
