@@ -565,6 +565,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.items = nullptr;
             sp.binom = e->binom.as<unsigned long long>();
             sp.time_index = e->ti.as<int>();
+            sp.has_ti = (a.mode == 1 && a.time_index != nullptr) ? 1 : 0;
             sp.chunk = chunk;
             sp.cap = 0;
             sp.cls = 0;

@@ -70,6 +70,7 @@ struct SweepParams
     const int2 *items;
     const unsigned long long *binom;
     const int *time_index;  // MODE 1, device, n entries
+    int has_ti;             // MODE 1: a time index was given (else all entries are 0 and the rule excludes nothing)
     float th;               // MODE 0: Th[l]; MODE 1 uniform ESS: th/sqrt(mean_ess-l-3); HET: alpha/2 quantile
     float t2;               // tanh(th)^2 for the fixed-threshold fast filter
     unsigned long long chunk;

@@ -252,9 +252,12 @@ __global__ void __launch_bounds__(THREADS) sweep_vec_kernel(SweepParams p)
                 }
                 if constexpr (MODE == 1)
                 {
+                    if (p.has_ti)
+                    {
 #pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (tmaxS > max(tiX, s_ti[min(g + u, d)])) livem &= ~(1u << u);
+                        for (int u = 0; u < 4; u++)
+                            if (tmaxS > max(tiX, s_ti[min(g + u, d)])) livem &= ~(1u << u);
+                    }
                 }
                 if (livem == 0u) continue;
                 // four tests, evaluated as two float2 pairs
