@@ -130,6 +130,7 @@ struct cusk_engine
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     int opt_hostprof = 0;
+    int opt_tmaj_validate_stride = 1;  // validating builds of sweep_tmaj check the unions whose per-lane count is a multiple of this (power of two)
     int opt_max_staged_classes = -1;  // >= 0: at most this many degree classes are staged in LDS (test hook for the unstaged kernels)
     int opt_tmaj_min_level = cusk::kTmajMinLevelDefault;  // first level swept by unions T = S + Y (sweep_tmaj.hip); 99 = never
     long long opt_chunk = 2048;

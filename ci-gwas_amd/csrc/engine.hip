@@ -260,7 +260,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 const unsigned long long per_row = sets / sp.chunk + 1ull;
                 if (per_row < (1ull << 40)) sp.grid_cap = std::min<long long>(item_cap, (long long)(per_row * (unsigned long long)n));
             }
-            sp.validate = e->opt_validate;
+            sp.validate = e->opt_validate ? std::max(1, e->opt_tmaj_validate_stride) : 0;
             if (pl.use_pair && !exact_only)
                 CUSK_HIP(e, launch_pair(a.mode, sp, pl.pair_lds, cs));
             else if (pl.tmaj && pl.use_fast && !exact_only)
@@ -914,6 +914,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_chunk = value;
     else if (k == "max_staged_classes")
         e->opt_max_staged_classes = (int)value;
+    else if (k == "tmaj_validate_stride" && value >= 1 && (value & (value - 1)) == 0)
+        e->opt_tmaj_validate_stride = (int)value;
     else if (k == "tmaj_min_level")
         e->opt_tmaj_min_level = (int)value;
     else if (k == "hostprof")

@@ -104,6 +104,8 @@ int cmd_cusk(int argc, char **argv)
                 std::cout << "[t] stage two level " << l << ": max degree " << st.max_degree[l] << ", " << st.edges[l]
                           << " edges, " << st.tests[l] << " tests, " << st.subsets[l] << " sets, " << st.rechecks[l]
                           << " rechecks, sweep " << st.kernel_ms[l] << " ms, level " << st.level_ms[l] << " ms" << std::endl;
+            std::cout << "[t] filter contradictions (option validate): stage one " << bs.stage[0].violations << ", stage two "
+                      << st.violations << "; exact fallbacks " << bs.stage[0].exact_fallbacks << " / " << st.exact_fallbacks << std::endl;
         }
         tm.mark("block pipeline");
     }

@@ -82,7 +82,8 @@ struct SweepParams
     unsigned long long *slots;  // this level's kCounterSlots x 4 spread counters: tests, subsets, removed, violations
     RecheckEntry *queue;
     unsigned long long qcap;
-    int validate;  // sweep_tmaj: check every certified verdict against double precision (cusk_stats.violations)
+    int validate;  // sweep_tmaj: > 0: check the certified verdicts of every validate-th union of a lane (power of two; 1 = all)
+                   // against double precision (cusk_stats.violations)
 };
 
 struct FinalizeParams

@@ -375,7 +375,7 @@ sweep_tmaj_kernel(SweepParams p)
                     unsurem &= ~skip;
                     ntests += NT - __popc(skip);
                 }
-                if (VALIDATE && !ill)
+                if (VALIDATE && !ill && ((nsub & (unsigned long long)(p.validate - 1)) == 0ull))
                 {  // certified verdicts against double precision, three quarters of the band as margin
 #pragma unroll
                     for (int j = 0; j < NT; j++)
