@@ -74,10 +74,12 @@ def test_tmaj_deepest_levels(cg, oracle, synth, nleaf, nhub, tmin):
 
 
 def test_tmaj_random_dense(cg, oracle, synth):
-    """dense random correlations at a loose threshold: many removals at every level, ill-conditioned sets included"""
+    """dense random correlations at a loose threshold: many removals at every level, ill-conditioned sets included
+    (validated by sampling: every fourth union of a lane, the form used for full-size runs)"""
     e = cg.Engine(0)
     e.set_option("tmaj_min_level", 2)
     e.set_option("validate", 1)
+    e.set_option("tmaj_validate_stride", 4)
     Cm = synth.random_corr(40, seed=23, k=300, strength=1.2)
     Th = cg.threshold_array(300, 0.1)
     st, ref = _check(cg, e, oracle, Cm, Th, 8)
