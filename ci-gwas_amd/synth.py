@@ -386,3 +386,69 @@ def write_phen_fast(path: str, Y: np.ndarray) -> None:
     with open(path, "w") as f:
         f.write("FID IID " + " ".join(f"T{k}" for k in range(p)) + "\n")
         f.write("".join(f"f{i} i{i} " + " ".join("NA" if np.isnan(v) else "%.9g" % v for v in cols[i]) + "\n" for i in range(N)))
+
+
+def rand_dag_corr(snp: int = 500, tr: int = 5, nl: int = 2, n: int = 16000, deg: float = 3.0, prob_pleio: float = 0.2,
+                  lo_mp: float = 0.001, hi_mp: float = 0.05, lo_pp: float = 0.001, hi_pp: float = 0.2, seed: int = 1,
+                  return_dag: bool = False):
+    """BASELINE config 1: the simulated correlation matrix of the reference's random-DAG simulator, restated in NumPy
+    (/root/reference/simulation/simulate_dag.R:3-98 `gen_rand_dag`, parameters :106-115 with SNP = 500, Tr = 5; own RNG
+    stream -- PCG64(BASE_SEED + seed) -- so not draw-for-draw identical to R's).
+
+    Variables in generation order: `snp` markers, `nl` latent confounders, `tr` traits (pq = snp + nl + tr).  Edges
+    only point forward in that order (:22-28 marker -> any later variable with probability deg / snp; :42-48 latent or
+    trait -> any later variable with probability min(deg / tr, 1)); a marker with exactly one trait child gets
+    pleiotropic edges to the other traits with probability prob_pleio each (:30-40: the whole draw replaces the other
+    entries, and only when it is not all zero).  Effects (:54-78): marker -> marker and latent / trait -> anything
+    U(lo_pp, hi_pp), marker -> latent / trait U(lo_mp, hi_mp), random sign.  Data (:80-91): a root is N(0, 1), a child
+    is its parents' linear combination g plus N(0, 1 - var(g)) noise (sample variance, n - 1 denominator as R's var).
+    Returns the (snp + tr) x (snp + tr) fp32 sample correlation of markers and traits (latents dropped, :120-127:
+    `cor(dag_data_mat)`), markers first -- the variable order of every n x n object on the path; with return_dag also
+    the 0/1 DAG and the effect matrix over all pq variables."""
+    rng = np.random.Generator(np.random.PCG64(BASE_SEED + 7919 * int(seed)))
+    pq = snp + nl + tr
+    t0 = snp + nl  # first trait
+    prob1 = deg / snp
+    prob2 = min(deg / tr, 1.0)
+    G = np.zeros((pq, pq), np.int8)
+    for i in range(snp):
+        G[i, i + 1:] = rng.random(pq - i - 1) < prob1
+    for i in range(snp):
+        iv = np.flatnonzero(G[i, t0:] == 1)
+        if iv.size == 1 and tr > 1:
+            draw = (rng.random(tr - 1) < prob_pleio).astype(np.int8)
+            if draw.any():
+                others = np.delete(np.arange(tr), iv[0])
+                G[i, t0 + others] = draw
+    for j in range(snp, pq):
+        G[j, j + 1:] = rng.random(pq - j - 1) < prob2
+
+    def effects(k, lo, hi):
+        return rng.uniform(lo, hi, k) * np.where(rng.standard_normal(k) < 0, -1.0, 1.0)
+
+    A = np.zeros((pq, pq), np.float64)
+    for i in range(snp):
+        d = np.flatnonzero(G[i, :snp])
+        A[i, d] = effects(d.size, lo_pp, hi_pp)
+        d = snp + np.flatnonzero(G[i, snp:])
+        A[i, d] = effects(d.size, lo_mp, hi_mp)
+    for i in range(snp, pq):
+        d = np.flatnonzero(G[i])
+        A[i, d] = effects(d.size, lo_pp, hi_pp)
+    X = np.empty((pq, n), np.float64)
+    for i in range(pq):
+        anc = np.flatnonzero(G[:, i])
+        if anc.size == 0:
+            X[i] = rng.standard_normal(n)
+        else:
+            g = A[anc, i] @ X[anc]
+            X[i] = g + rng.standard_normal(n) * np.sqrt(max(1.0 - g.var(ddof=1), 0.0))
+    keep = np.concatenate([np.arange(snp), np.arange(t0, pq)])
+    Cm = np.corrcoef(X[keep]).astype(np.float32)
+    Cm = np.triu(Cm, 1)
+    Cm = Cm + Cm.T
+    np.fill_diagonal(Cm, 1.0)
+    Cm = np.ascontiguousarray(Cm, np.float32)
+    if return_dag:
+        return Cm, G, A
+    return Cm

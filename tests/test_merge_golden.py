@@ -61,6 +61,19 @@ def test_merge_mirror_writes_the_files_the_reference_wrote(tmp_path, capsys):
     assert np.all(np.diff(ixs) > 0) and not np.any((ixs >= a) & (ixs <= b))
 
 
+def test_merge_oracle_reproduces_the_reference_files(tmp_path):
+    """the checker of the workflow chain test (oracle/merge_oracle.py) is pinned by the files the reference wrote"""
+    from oracle import merge_oracle as MO
+
+    MO.write_mm(MO.merge(os.path.join(G, "inputs", "blocks.txt"), os.path.join(G, "blocks") + "/"), str(tmp_path / "merged_blocks"))
+    _same_dir(os.path.join(G, "merged"), str(tmp_path))
+    d = tmp_path / "cm"
+    shutil.copytree(os.path.join(G, "cuskss_merged_raw"), d)
+    shutil.copy(os.path.join(G, "merged", "merged_blocks.ixs"), d)
+    MO.write_mm(MO.reformat_cuskss_merged(str(d)), f"{d}/cuskss_merged")
+    _same_dir(os.path.join(G, "cuskss_merged"), str(d), sorted(os.listdir(os.path.join(G, "cuskss_merged"))))
+
+
 def test_cli_shim_builds_the_argv_of_the_reference_cli():
     """argv lists captured from the reference's ci-gwas.py handlers (subprocess.run intercepted)"""
     from cigwas_amd import cli
