@@ -73,6 +73,9 @@ SYMBOLS = {
     "cusk_engine_set_row_shard": (_i, [_vp, _i, _i, _vp, _vp, _i]),
     "cusk_run_skeleton": (_i, [_vp, _vp, _i, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
+    "cusk_run_skeleton_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(CuskStats)]),
+    "cusk_result_adj_bits_blocks": (_i, [_vp, _vp]),
+    "cusk_gather_rows": (_i, [_vp, _vp, _i, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i]),
     "cusk_result_n": (_i, [_vp]),
     "cusk_result_adj_bits_dev": (_vp, [_vp]),
     "cusk_result_words": (_i, [_vp]),
@@ -82,6 +85,8 @@ SYMBOLS = {
     "cusk_result_sepset_dense": (_i, [_vp, _vp]),
     "cusk_result_sepsets": (_ll, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cusk_corr_build": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
+    "cusk_corr_build_batch_mxp": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp, _i, _vp, _vp]),
+    "cusk_corr_build_batch_mxm": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp, _vp, _i, _vp]),
     "cusk_corr_build_begin": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp]),
     "cusk_corr_build_end": (_i, [_vp, _vp]),
     "cusk_corr_timing": (None, [_vp, _vp]),

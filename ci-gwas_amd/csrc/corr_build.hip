@@ -373,14 +373,39 @@ constexpr int kKS4 = kKB4 / 64;  // MFMA steps per K block
 // band_w = 0: square output C[n x n], both triangles, upper-triangle tiles enumerated along blockIdx.x.
 // band_w > 0 (mps block): banded output C[i * band_w + (j - i - 1)] for 0 < j - i <= band_w, tile (blockIdx.x,
 // blockIdx.x + blockIdx.y).
+// btile != nullptr (cusk_corr_build_batch): many LD blocks in one launch -- workgroup w computes tile (btile[w].y, btile[w].z)
+// of block btile[w].x, whose genotypes start at marker bblk[..].bed_row0 of `bed` and whose matrix lies on the diagonal of
+// the n x n batch allocation at variable bblk[..].base.
+struct CorrBatchBlock
+{
+    unsigned long long bed_row0;  // first marker of the block (row of the staged .bed; index into mean / sd)
+    int m;                        // markers of the block
+    int base;                     // first variable of the block in the batch allocation
+    long long mxp_off;            // first marker of the block in the compact marker x trait output
+};
+
 template <bool FAST>
-__global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__restrict__ bed, float *C, size_t m, size_t N,
-                                                          size_t clb, size_t n, int tiles, size_t band_w)
+__global__ void __launch_bounds__(256, 2) mxm_fp4_kernel(const unsigned char *__restrict__ bed_in, float *C_in, size_t m_in, size_t N,
+                                                          size_t clb, size_t n, int tiles, size_t band_w,
+                                                          const int4 *__restrict__ btile, const CorrBatchBlock *__restrict__ bblk)
 {
     __shared__ v4i sA[3][kKS4][2][kMT];
     __shared__ v4i sB[3][kKS4][2][kMT];
     int t = blockIdx.x, bi = 0;
-    if (band_w == 0)
+    const unsigned char *__restrict__ bed = bed_in;
+    float *C = C_in;
+    size_t m = m_in;
+    if (btile != nullptr)
+    {
+        const int4 bt = btile[blockIdx.x];
+        const CorrBatchBlock bb = bblk[bt.x];
+        bed = bed_in + bb.bed_row0 * clb;
+        C = C_in + (size_t)bb.base * n + bb.base;
+        m = (size_t)bb.m;
+        bi = bt.y;
+        t = bt.z;
+    }
+    else if (band_w == 0)
     {
         int rem = t, len = tiles;
         while (rem >= len)
@@ -709,13 +734,27 @@ __global__ void __launch_bounds__(64 * kMxpWaves) mxp_mfma_kernel(const unsigned
                                                                   const float *__restrict__ mean,
                                                                   const float *__restrict__ sd, float *C, float *mxp, size_t m,
                                                                   size_t N, size_t p, size_t clb, size_t n, size_t p0,
-                                                                  int pcount)
+                                                                  int pcount, const int2 *__restrict__ mtile,
+                                                                  const CorrBatchBlock *__restrict__ bblk)
 {
     __shared__ float s_part[kMxpWaves / 2][3][16][64];  // partial accumulators of the upper half of the waves
     __shared__ float s_sv[kMxpWaves][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r32 = lane & 31, kh = lane >> 5;
-    const size_t mk = (size_t)blockIdx.x * 32 + r32;  // A side: this lane's marker
+    size_t tile32 = blockIdx.x;
+    if (mtile != nullptr)
+    {  // batched build: tile mtile[w].y of block mtile[w].x (see mxm_fp4_kernel)
+        const int2 mt = mtile[blockIdx.x];
+        const CorrBatchBlock bb = bblk[mt.x];
+        bed += bb.bed_row0 * clb;
+        mean += bb.bed_row0;
+        sd += bb.bed_row0;
+        if (C) C += (size_t)bb.base * n + bb.base;
+        if (mxp) mxp += (size_t)bb.mxp_off * p;
+        m = (size_t)bb.m;
+        tile32 = (size_t)mt.y;
+    }
+    const size_t mk = tile32 * 32 + r32;  // A side: this lane's marker
     const bool mok = mk < m;
     const unsigned char *rowp = bed + (mok ? mk : 0) * clb;
     const bool tok = r32 < pcount;  // B side: this lane's trait
@@ -861,7 +900,7 @@ __global__ void __launch_bounds__(64 * kMxpWaves) mxp_mfma_kernel(const unsigned
     for (int r = 0; r < 16; r++)
     {
         const int il = (r & 3) + 8 * (r >> 2) + 4 * kh;
-        const size_t mi = (size_t)blockIdx.x * 32 + il;
+        const size_t mi = tile32 * 32 + il;
         if (mi < m && tok)
         {
             const float cnt = s_sv[0][il] - acc_vn[r];
@@ -1025,10 +1064,10 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_d) & 15u) == 0);
         if (e->opt_corr_fp4 && rows16)
             hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev,
-                               m, N, clb, n, tiles, (size_t)0);
+                               m, N, clb, n, tiles, (size_t)0, (const int4 *)nullptr, (const CorrBatchBlock *)nullptr);
         else if (e->opt_corr_fp4)
             hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev,
-                               m, N, clb, n, tiles, (size_t)0);
+                               m, N, clb, n, tiles, (size_t)0, (const int4 *)nullptr, (const CorrBatchBlock *)nullptr);
         else
             hipLaunchKernelGGL(mxm_mfma_kernel, dim3((unsigned)nt), dim3(256), 0, s, bed_d, C_dev, m,
                                N, clb, n, tiles);
@@ -1053,11 +1092,13 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
             if (fast)
                 hipLaunchKernelGGL(mxp_mfma_kernel<true>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
                                    bed_d, phen_d, mean_d,
-                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc, (const int2 *)nullptr,
+                                   (const CorrBatchBlock *)nullptr);
             else
                 hipLaunchKernelGGL(mxp_mfma_kernel<false>, dim3((unsigned)((m + 31) / 32)), dim3(64 * kMxpWaves), 0, s,
                                    bed_d, phen_d, mean_d,
-                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc);
+                                   std_d, C_dev, mxp_d, m, N, p, clb, n, p0, (int)pc, (const int2 *)nullptr,
+                                   (const CorrBatchBlock *)nullptr);
         }
     }
     if (C_dev && p > 1)
@@ -1101,6 +1142,144 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
     return CUSK_OK;
 }
 
+// ---------------------------------------------------------------------------
+// batched build: the correlation matrices of many LD blocks in one set of launches (cusk_corr_build_batch_*)
+// ---------------------------------------------------------------------------
+
+// per block: the trait x trait correlations (computed once, the same for every block: cli.cpp:597-649 writes them into
+// every block's matrix) and the unit diagonal
+__global__ void __launch_bounds__(256) batch_finish_kernel(float *C, size_t n, const CorrBatchBlock *__restrict__ bblk,
+                                                            const int *__restrict__ kept, const float *__restrict__ pxp, int p)
+{
+    const CorrBatchBlock bb = bblk[kept[blockIdx.x]];
+    float *Cb = C + (size_t)bb.base * n + bb.base;
+    const int nb = bb.m + p;
+    for (int i = threadIdx.x; i < nb; i += 256) Cb[(size_t)i * n + i] = 1.0f;
+    for (int e = threadIdx.x; e < p * p; e += 256)
+    {
+        const int a = e / p, b = e % p;
+        if (a != b) Cb[(size_t)(bb.m + a) * n + bb.m + b] = pxp[(size_t)a * p + b];
+    }
+}
+
+// Phase one: marker x trait correlations of every block (into the batch allocation and into a compact host array, block
+// after block: the prefilter of cli.cpp:561-576 is the caller's).  Waits for the result.
+// Phase two: marker x marker tiles, trait x trait, diagonal of the blocks the caller keeps; asynchronous on the engine's
+// stream (the sweep that follows is ordered behind it).
+int corr_build_batch_impl(cusk_engine *e, int phase, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                          const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker, const int *markers,
+                          const int *base, const unsigned char *keep, size_t n, float *C_dev, float *mxp_host)
+{
+    if (!e || !bed_dev || !phen_dev || !mean_dev || !std_dev || !first_marker || !markers || !base || !C_dev || nblk <= 0 || N == 0)
+        return fail(e, CUSK_ERR_ARG, "bad arguments");
+    if (!(is_device_pointer(bed_dev) && is_device_pointer(phen_dev) && is_device_pointer(mean_dev) && is_device_pointer(std_dev)))
+        return fail(e, CUSK_ERR_ARG, "cusk_corr_build_batch needs device-resident inputs (cusk_blockset_stage)");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    hipStream_t s = e->stream;
+    const size_t clb = (N + 3) / 4;
+    // tables: blocks, then the tiles of this phase
+    std::vector<CorrBatchBlock> blk((size_t)nblk);
+    long long moff = 0;
+    for (int b = 0; b < nblk; b++)
+    {
+        if (markers[b] <= 0 || base[b] < 0 || (size_t)base[b] + (size_t)markers[b] + p > n)
+            return fail(e, CUSK_ERR_ARG, "cusk_corr_build_batch: block outside the batch allocation");
+        blk[(size_t)b] = CorrBatchBlock{(unsigned long long)first_marker[b], markers[b], base[b], moff};
+        moff += markers[b];
+    }
+    const size_t b_blk = sizeof(CorrBatchBlock) * (size_t)nblk;
+    std::vector<int4> tiles4;
+    std::vector<int2> tiles2;
+    std::vector<int> kept;
+    if (phase == 1)
+    {
+        for (int b = 0; b < nblk; b++)
+            for (int t = 0; t < (markers[b] + 31) / 32; t++) tiles2.push_back(make_int2(b, t));
+    }
+    else
+    {
+        for (int b = 0; b < nblk; b++)
+        {
+            if (keep && !keep[b]) continue;
+            kept.push_back(b);
+            const int tl = (markers[b] + kMT - 1) / kMT;
+            for (int bi = 0; bi < tl; bi++)
+                for (int bj = bi; bj < tl; bj++) tiles4.push_back(make_int4(b, bi, bj, 0));
+        }
+        if (kept.empty()) return CUSK_OK;
+    }
+    const size_t b_t = (phase == 1) ? sizeof(int2) * tiles2.size() : sizeof(int4) * tiles4.size();
+    const size_t b_k = sizeof(int) * kept.size();
+    const size_t o_t = (b_blk + 15) & ~(size_t)15, o_k = o_t + ((b_t + 15) & ~(size_t)15), total = o_k + ((b_k + 15) & ~(size_t)15) + 16;
+    // one pinned staging area per phase: phase one waits for its stream at the end, phase two is followed by a run that does
+    const int slot = phase == 1 ? 0 : 1;
+    if (total > e->corr_tab_pinned_cap[slot])
+    {
+        if (e->corr_tab_pinned[slot]) (void)hipHostFree(e->corr_tab_pinned[slot]);
+        e->corr_tab_pinned[slot] = nullptr;
+        e->corr_tab_pinned_cap[slot] = 0;
+        CUSK_HIP(e, hipHostMalloc(&e->corr_tab_pinned[slot], total * 2));
+        e->corr_tab_pinned_cap[slot] = total * 2;
+    }
+    char *h = static_cast<char *>(e->corr_tab_pinned[slot]);
+    std::memcpy(h, blk.data(), b_blk);
+    if (phase == 1)
+        std::memcpy(h + o_t, tiles2.data(), b_t);
+    else
+    {
+        std::memcpy(h + o_t, tiles4.data(), b_t);
+        std::memcpy(h + o_k, kept.data(), b_k);
+    }
+    CUSK_HIP(e, e->corr_tab[slot].ensure(total));
+    CUSK_HIP(e, hipMemcpyAsync(e->corr_tab[slot].p, h, total, hipMemcpyHostToDevice, s));
+    const char *d = e->corr_tab[slot].as<char>();
+    const CorrBatchBlock *blk_d = reinterpret_cast<const CorrBatchBlock *>(d);
+    if (phase == 1)
+    {
+        if (p == 0) return CUSK_OK;
+        float *mxp_d = nullptr;
+        if (mxp_host)
+        {
+            CUSK_HIP(e, e->mxp_dev.ensure(sizeof(float) * (size_t)moff * p));
+            mxp_d = e->mxp_dev.as<float>();
+        }
+        const bool fast = (clb % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(bed_dev) & 3u) == 0) &&
+                          ((reinterpret_cast<uintptr_t>(phen_dev) & 15u) == 0);
+        const int2 *mt_d = reinterpret_cast<const int2 *>(d + o_t);
+        for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
+        {
+            const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
+            if (fast)
+                hipLaunchKernelGGL(mxp_mfma_kernel<true>, dim3((unsigned)tiles2.size()), dim3(64 * kMxpWaves), 0, s, bed_dev, phen_dev,
+                                   mean_dev, std_dev, C_dev, mxp_d, (size_t)0, N, p, clb, n, p0, (int)pc, mt_d, blk_d);
+            else
+                hipLaunchKernelGGL(mxp_mfma_kernel<false>, dim3((unsigned)tiles2.size()), dim3(64 * kMxpWaves), 0, s, bed_dev, phen_dev,
+                                   mean_dev, std_dev, C_dev, mxp_d, (size_t)0, N, p, clb, n, p0, (int)pc, mt_d, blk_d);
+        }
+        CUSK_HIP(e, hipGetLastError());
+        if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(mxp_host, mxp_d, sizeof(float) * (size_t)moff * p, hipMemcpyDeviceToHost, s));
+        CUSK_HIP(e, hipStreamSynchronize(s));
+        return CUSK_OK;
+    }
+    const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_dev) & 15u) == 0);
+    const int4 *bt_d = reinterpret_cast<const int4 *>(d + o_t);
+    if (rows16)
+        hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)tiles4.size()), dim3(256), 0, s, bed_dev, C_dev, (size_t)0, N, clb, n, 0,
+                           (size_t)0, bt_d, blk_d);
+    else
+        hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)tiles4.size()), dim3(256), 0, s, bed_dev, C_dev, (size_t)0, N, clb, n, 0,
+                           (size_t)0, bt_d, blk_d);
+    // trait x trait once (a p x p matrix of its own: m = 0, leading dimension p), then into every kept block with the diagonal
+    CUSK_HIP(e, e->pxp_dev.ensure(sizeof(float) * std::max<size_t>(p * p, 1)));
+    if (p > 1)
+        hipLaunchKernelGGL(pxp_kernel, dim3((unsigned)(p * (p - 1) / 2)), dim3(256), 0, s, phen_dev, e->pxp_dev.as<float>(), (size_t)0, N, p,
+                           p);
+    hipLaunchKernelGGL(batch_finish_kernel, dim3((unsigned)kept.size()), dim3(256), 0, s, C_dev, n, blk_d,
+                       reinterpret_cast<const int *>(d + o_k), e->pxp_dev.as<float>(), (int)p);
+    CUSK_HIP(e, hipGetLastError());
+    return CUSK_OK;
+}
+
 // forward row sums of |band|: one thread per row, float accumulation in column order (the reference's host loop,
 // corr_host.cu:112-128, so the sums are bit-identical)
 __global__ void band_row_abs_sums_kernel(const float *__restrict__ band, size_t m, size_t w, float *sums)
@@ -1131,10 +1310,10 @@ int corr_banded_impl(cusk_engine *e, const unsigned char *bed, size_t m, size_t 
     const bool rows16 = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(e->bed_dev.p) & 15u) == 0);
     if (rows16)
         hipLaunchKernelGGL(mxm_fp4_kernel<true>, dim3((unsigned)tiles, ndj), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
-                           band.as<float>(), m, N, clb, m, tiles, width);
+                           band.as<float>(), m, N, clb, m, tiles, width, (const int4 *)nullptr, (const CorrBatchBlock *)nullptr);
     else
         hipLaunchKernelGGL(mxm_fp4_kernel<false>, dim3((unsigned)tiles, ndj), dim3(256), 0, s, e->bed_dev.as<unsigned char>(),
-                           band.as<float>(), m, N, clb, m, tiles, width);
+                           band.as<float>(), m, N, clb, m, tiles, width, (const int4 *)nullptr, (const CorrBatchBlock *)nullptr);
     hipLaunchKernelGGL(band_row_abs_sums_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, band.as<float>(), m, width,
                        sums.as<float>());
     CUSK_HIP(e, hipGetLastError());
@@ -1211,6 +1390,22 @@ extern "C" int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const f
 
 // The build of the next block while the current one is swept: begin enqueues everything on the engine's third stream and
 // returns; end waits for it and hands over the marker x trait correlations.  One build in flight per engine.
+extern "C" int cusk_corr_build_batch_mxp(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                                         const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                                         const int *markers, const int *base, int n, float *C_dev, float *mxp_host)
+{
+    return corr_build_batch_impl(e, 1, bed_dev, phen_dev, mean_dev, std_dev, N, p, nblk, first_marker, markers, base, nullptr, (size_t)n,
+                                 C_dev, mxp_host);
+}
+
+extern "C" int cusk_corr_build_batch_mxm(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                                         const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                                         const int *markers, const int *base, const unsigned char *keep, int n, float *C_dev)
+{
+    return corr_build_batch_impl(e, 2, bed_dev, phen_dev, mean_dev, std_dev, N, p, nblk, first_marker, markers, base, keep, (size_t)n,
+                                 C_dev, nullptr);
+}
+
 extern "C" int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N,
                                      size_t p, const float *mean_dev, const float *std_dev, float *C_dev)
 {

@@ -99,6 +99,11 @@ struct cusk_engine
     cusk::DevBuf scratch_a, scratch_b;  // result read-out / gather scratch (no hipMalloc / hipFree per call)
     const float *last_C = nullptr;  // matrix of the last run (the winners' z is computed from it on request)
     int last_levels = 0;
+    // batched runs (cusk_run_skeleton_batch): block table of the last run and its per-row view on the device
+    std::vector<int> batch_lo, batch_hi;
+    cusk::DevBuf row_range, row_blk, blk_woff;
+    void *batch_pinned = nullptr;  // staging of the per-row tables
+    size_t batch_pinned_cap = 0;
     cusk::DevBuf rv, rpos, sel, wpre;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors
@@ -154,7 +159,10 @@ struct cusk_engine
     size_t shard_host_cap = 0;
 
     // correlation build scratch
-    cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev;
+    cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev, pxp_dev;
+    cusk::DevBuf corr_tab[2];  // batched build: block / tile tables of phase one (marker x trait) and two (marker x marker)
+    void *corr_tab_pinned[2] = {nullptr, nullptr};
+    size_t corr_tab_pinned_cap[2] = {0, 0};
     hipEvent_t ev_corr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     float corr_ms[4] = {0, 0, 0, 0};
 };

@@ -70,6 +70,10 @@ struct RunArgs
     const int *time_index;  // host, n entries or null
     int n;
     int maxlevel;
+    // batched run: per row the column range of its block (device, n entries) and the largest range; nullptr = one block
+    const int2 *row_range = nullptr;
+    int max_span = 0;
+    long long level0_pairs = 0;  // unordered pairs inside the blocks (the level-0 tests of a batched run)
 };
 
 // layout of the per-run control block (device) and of its pinned mirror (host)
@@ -178,15 +182,21 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     {
         float th0 = a.Th[0];
         if (a.mode == 1 && !het) th0 = (float)((double)a.Th[0] / std::sqrt((double)a.ess_uniform - 3.0));
-        CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
-                                  e->opt_assume_symmetric ? nullptr : dsym, s));
-        if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
+        if (a.row_range)
+            CUSK_HIP(e, launch_level0_batch(a.C, e->adj.as<unsigned long long>(), e->adj0.as<unsigned long long>(), e->deg.as<int>(), n,
+                                            words, a.row_range, th0, s));
+        else
+        {
+            CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
+                                      e->opt_assume_symmetric ? nullptr : dsym, s));
+            if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
+        }
     }
     CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
     hp_mark("l0_enq");
     local.max_degree[0] = n - 1;
     local.edges[0] = (long long)n * (n - 1);
-    local.tests[0] = (long long)n * (n - 1) / 2;
+    local.tests[0] = a.row_range ? a.level0_pairs : (long long)n * (n - 1) / 2;
     local.canonical_tests[0] = a.mode == 0 ? local.tests[0] : 0;
     local.levels_run = 1;
 
@@ -344,7 +354,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         return CUSK_OK;
     };
 
-    if (last_level >= 1) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
+    if (last_level >= 1 && !a.row_range) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
 
     // which classes can be staged in LDS in this mode
     int staged_classes = 0;
@@ -460,7 +470,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             pa.shard_world = e->shard_world;
             pa.gate = e->hgate_dev + l;
             pa.seq = run_seq;
-            pa.sym = (l == 1 && !e->opt_assume_symmetric) ? dsym : nullptr;
+            pa.sym = (l == 1 && !e->opt_assume_symmetric && !a.row_range) ? dsym : nullptr;
             pa.blocks = e->planblk.as<unsigned long long>();
             pa.blk_seq = ++e->plan_seq;
             if (first_build && e->binom_rows <= 0)
@@ -477,7 +487,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 int rc = wait_gate(1);
                 if (rc != CUSK_OK) return rc;
                 hp_mark("gate1");
-                symmetric = (e->hgate[1].sym == 0) || (e->opt_assume_symmetric != 0);
+                symmetric = (e->hgate[1].sym == 0) || (e->opt_assume_symmetric != 0) || (a.row_range != nullptr);
                 cap_edges = std::max<long long>(e->hgate[1].total_edges, 1);
                 maxdeg1 = e->hgate[1].maxdeg;
                 for (int k = 0; k < 2; k++)
@@ -549,7 +559,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             // 2. the neighbour lists (no host dependency)
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), off_l, e->nbr[cs].as<int>(),
                                         (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr, n, words,
-                                        (l == 1 && (pl.use_rows || a.mode == 0)) ? e->wpre.as<int>() : nullptr, dcnt + l, s));
+                                        (l == 1 && (pl.use_rows || a.mode == 0)) ? e->wpre.as<int>() : nullptr, dcnt + l, a.row_range, s));
 
             SweepParams &sp = pl.sp;
             sp.C = a.C;
@@ -572,6 +582,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             sp.item_cap = item_cap;
             sp.grid_cap = item_cap;
             sp.cnt = dcnt + l;
+            sp.row_range = a.row_range;
+            sp.max_span = a.row_range ? a.max_span : n;
             sp.slots = dslots + (size_t)l * kCounterSlots * 4;
             if (a.mode == 0)
                 sp.th = a.Th[l];
@@ -851,7 +863,15 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
 {
     if (!e) return;
     (void)hipSetDevice(e->device);
+    // every stream is idle before anything they may still use is released (an ahead correlation build on stream3 reads the
+    // planes / mxp buffers and writes the pinned landing buffer)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
+    if (e->stream3) (void)hipStreamSynchronize(e->stream3);
+    for (DevBuf *b : {&e->row_range, &e->row_blk, &e->blk_woff, &e->pxp_dev, &e->corr_tab[0], &e->corr_tab[1]}) b->release();
+    for (void *ph : e->corr_tab_pinned)
+        if (ph) (void)hipHostFree(ph);
+    if (e->batch_pinned) (void)hipHostFree(e->batch_pinned);
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
                       &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_s, &e->den_x, &e->den_y, &e->den_l,
                       &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->planblk, &e->scratch_a, &e->scratch_b, &e->bed_dev, &e->phen_dev,
@@ -875,8 +895,6 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     for (int l = 0; l < kLevels; l++)
         for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
             if (ev) (void)hipEventDestroy(ev);
-    if (e->stream2) (void)hipStreamSynchronize(e->stream2);
-    if (e->stream3) (void)hipStreamSynchronize(e->stream3);
     for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -971,6 +989,7 @@ extern "C" int cusk_run_skeleton(cusk_engine *e, const float *C_dev, int n, cons
                                  cusk_stats *stats)
 {
     if (!e) return CUSK_ERR_ARG;
+    e->batch_lo.clear();
     RunArgs a{};
     a.mode = 0;
     a.C = C_dev;
@@ -980,11 +999,140 @@ extern "C" int cusk_run_skeleton(cusk_engine *e, const float *C_dev, int n, cons
     return run_levels(e, a, stats);
 }
 
+// Batched Skeleton run: `nblk` independent blocks laid out along the diagonal of one n x n allocation (include/cusk_hip.h).
+// One plan / fill / sweep / finalise chain per level serves every block: after level 0 the engine only works on CSR rows,
+// and a row never meets a column outside its block, so nothing but level 0 and the level-1 row staging knows about blocks.
+extern "C" int cusk_run_skeleton_batch(cusk_engine *e, const float *C_dev, int n, int nblk, const int *lo, const int *hi,
+                                       const float *Th, int maxlevel, cusk_stats *stats)
+{
+    if (!e) return CUSK_ERR_ARG;
+    if (!C_dev || !lo || !hi || !Th || n <= 0 || nblk <= 0) return fail(e, CUSK_ERR_ARG, "bad arguments");
+    if (e->shard_world > 1) return fail(e, CUSK_ERR_ARG, "batched runs are not row-sharded");
+    int prev = 0, span = 0;
+    long long pairs0 = 0;
+    for (int b = 0; b < nblk; b++)
+    {
+        if ((lo[b] & 63) != 0 || lo[b] < prev || hi[b] < lo[b] || hi[b] > n)
+            return fail(e, CUSK_ERR_ARG, "cusk_run_skeleton_batch: block bases must be ascending multiples of 64 inside the matrix");
+        prev = hi[b];
+        span = std::max(span, hi[b] - lo[b]);
+        pairs0 += (long long)(hi[b] - lo[b]) * (hi[b] - lo[b] - 1) / 2;
+    }
+    CUSK_HIP(e, hipSetDevice(e->device));
+    // per-row tables: column range of the row's block, block number (-1: padding), and per block the offset of its packed
+    // bitmap (cusk_result_adj_bits_blocks)
+    const size_t bytes_rr = sizeof(int2) * (size_t)n, bytes_rb = sizeof(int) * (size_t)n, bytes_wo = sizeof(long long) * (size_t)nblk;
+    const size_t need = bytes_rr + bytes_rb + bytes_wo;
+    if (need > e->batch_pinned_cap)
+    {
+        if (e->batch_pinned) (void)hipHostFree(e->batch_pinned);
+        e->batch_pinned = nullptr;
+        e->batch_pinned_cap = 0;
+        CUSK_HIP(e, hipHostMalloc(&e->batch_pinned, need + need / 2));
+        e->batch_pinned_cap = need + need / 2;
+    }
+    // the previous run's copies out of this staging buffer have completed: every run ends with a stream synchronisation
+    int2 *rr = static_cast<int2 *>(e->batch_pinned);
+    int *rb = reinterpret_cast<int *>(static_cast<char *>(e->batch_pinned) + bytes_rr);
+    long long *wo = reinterpret_cast<long long *>(static_cast<char *>(e->batch_pinned) + bytes_rr + bytes_rb);
+    for (int r = 0; r < n; r++)
+    {
+        rr[r] = make_int2(0, 0);
+        rb[r] = -1;
+    }
+    long long woff = 0;
+    for (int b = 0; b < nblk; b++)
+    {
+        for (int r = lo[b]; r < hi[b]; r++)
+        {
+            rr[r] = make_int2(lo[b], hi[b]);
+            rb[r] = b;
+        }
+        wo[b] = woff;
+        woff += (long long)(hi[b] - lo[b]) * ((hi[b] - lo[b] + 63) / 64);
+    }
+    CUSK_HIP(e, e->row_range.ensure(bytes_rr));
+    CUSK_HIP(e, e->row_blk.ensure(bytes_rb));
+    CUSK_HIP(e, e->blk_woff.ensure(bytes_wo));
+    CUSK_HIP(e, hipMemcpyAsync(e->row_range.p, rr, bytes_rr, hipMemcpyHostToDevice, e->stream));
+    CUSK_HIP(e, hipMemcpyAsync(e->row_blk.p, rb, bytes_rb, hipMemcpyHostToDevice, e->stream));
+    CUSK_HIP(e, hipMemcpyAsync(e->blk_woff.p, wo, bytes_wo, hipMemcpyHostToDevice, e->stream));
+    e->batch_lo.assign(lo, lo + nblk);
+    e->batch_hi.assign(hi, hi + nblk);
+    RunArgs a{};
+    a.mode = 0;
+    a.C = C_dev;
+    a.Th = Th;
+    a.n = n;
+    a.maxlevel = maxlevel;
+    a.row_range = e->row_range.as<int2>();
+    a.max_span = span;
+    a.level0_pairs = pairs0;
+    const int rc = run_levels(e, a, stats);
+    if (rc != CUSK_OK) e->batch_lo.clear();
+    return rc;
+}
+
+// the adjacency of the last batched run, block by block: rows lo..hi-1 of block b, each as the (hi - lo + 63) / 64 words of
+// the block's own columns (bit j = local variable j; bases are multiples of 64), blocks back to back
+extern "C" int cusk_result_adj_bits_blocks(cusk_engine *e, uint64_t *out_host)
+{
+    if (!e || !e->have_result || e->batch_lo.empty() || !out_host) return fail(e, CUSK_ERR_STATE, "no batched result");
+    CUSK_HIP(e, hipSetDevice(e->device));
+    long long total = 0;
+    for (size_t b = 0; b < e->batch_lo.size(); b++)
+        total += (long long)(e->batch_hi[b] - e->batch_lo[b]) * ((e->batch_hi[b] - e->batch_lo[b] + 63) / 64);
+    if (total == 0) return CUSK_OK;
+    CUSK_HIP(e, e->scratch_b.ensure(sizeof(unsigned long long) * (size_t)total));
+    CUSK_HIP(e, launch_pack_block_bits(e->adj.as<unsigned long long>(), e->n, e->words, e->row_range.as<int2>(), e->row_blk.as<int>(),
+                                       e->blk_woff.as<long long>(), e->scratch_b.as<unsigned long long>(), e->stream));
+    CUSK_HIP(e, hipMemcpyAsync(out_host, e->scratch_b.p, sizeof(unsigned long long) * (size_t)total, hipMemcpyDeviceToHost, e->stream));
+    CUSK_HIP(e, hipStreamSynchronize(e->stream));
+    return CUSK_OK;
+}
+
+// out[row_out[t] + c] = M[row_src[t] * n + idx[row_first[t] + c]], c < row_k[t], for nrows rows t: the sub-matrices of many
+// blocks in one launch (stage-two matrices on the diagonal of a batch allocation: out on the device; the retained
+// sub-matrices of the results: out on the host).  All index arrays are host memory.
+extern "C" int cusk_gather_rows(cusk_engine *e, const float *M_dev, int n, const int *idx_host, long long nidx, const int *row_src,
+                                const int *row_k, const long long *row_first, const long long *row_out, long long nrows,
+                                float *out, long long out_count, int out_on_device)
+{
+    if (!e || !M_dev || !idx_host || !row_src || !row_k || !row_first || !row_out || !out || nrows < 0 || nidx < 0)
+        return fail(e, CUSK_ERR_ARG, "bad arguments");
+    if (nrows == 0) return CUSK_OK;
+    CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t b_idx = sizeof(int) * (size_t)nidx, b_src = sizeof(int) * (size_t)nrows, b_ll = sizeof(long long) * (size_t)nrows;
+    const size_t o_src = (b_idx + 15) & ~(size_t)15, o_k = o_src + ((b_src + 15) & ~(size_t)15), o_first = o_k + ((b_src + 15) & ~(size_t)15),
+                 o_out = o_first + b_ll, total = o_out + b_ll;
+    CUSK_HIP(e, e->scratch_a.ensure(total));
+    char *d = e->scratch_a.as<char>();
+    hipStream_t s = e->stream;
+    CUSK_HIP(e, hipMemcpyAsync(d, idx_host, b_idx, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(d + o_src, row_src, b_src, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(d + o_k, row_k, b_src, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(d + o_first, row_first, b_ll, hipMemcpyHostToDevice, s));
+    CUSK_HIP(e, hipMemcpyAsync(d + o_out, row_out, b_ll, hipMemcpyHostToDevice, s));
+    float *dst = out;
+    if (!out_on_device)
+    {
+        CUSK_HIP(e, e->scratch_b.ensure(sizeof(float) * (size_t)out_count));
+        dst = e->scratch_b.as<float>();
+    }
+    CUSK_HIP(e, launch_gather_rows(M_dev, n, reinterpret_cast<const int *>(d), reinterpret_cast<const int *>(d + o_src),
+                                   reinterpret_cast<const int *>(d + o_k), reinterpret_cast<const long long *>(d + o_first),
+                                   reinterpret_cast<const long long *>(d + o_out), nrows, dst, s));
+    if (!out_on_device) CUSK_HIP(e, hipMemcpyAsync(out, dst, sizeof(float) * (size_t)out_count, hipMemcpyDeviceToHost, s));
+    CUSK_HIP(e, hipStreamSynchronize(s));  // the host arrays may go away; the scratch is reused by the next call
+    return CUSK_OK;
+}
+
 extern "C" int cusk_run_hetcor(cusk_engine *e, const float *C_dev, const float *N_dev, float ess_uniform,
                                const int *G_init_dev, int n, float th, int maxlevel, const int *time_index,
                                cusk_stats *stats)
 {
     if (!e) return CUSK_ERR_ARG;
+    e->batch_lo.clear();
     RunArgs a{};
     a.mode = 1;
     a.C = C_dev;

@@ -84,6 +84,11 @@ struct SweepParams
     unsigned long long qcap;
     int validate;  // sweep_tmaj: > 0: check the certified verdicts of every validate-th union of a lane (power of two; 1 = all)
                    // against double precision (cusk_stats.violations)
+    // Batched runs (cusk_run_skeleton_batch): the matrix is block diagonal -- several independent LD blocks laid out along
+    // the diagonal of one n x n allocation, block bases multiples of 64 -- and row r only ever meets the columns
+    // [row_range[r].x, row_range[r].y) of its own block (padding rows: an empty range).  nullptr: one block, [0, n).
+    const int2 *row_range;
+    int max_span;  // largest y - x of row_range (n without it): sizes the LDS row of the level-1 kernel
 };
 
 struct FinalizeParams
@@ -262,9 +267,13 @@ size_t sweep_vec_lds_bytes(int cls);
 // sweep_level.hip: level 0, compaction, level-1 pair kernel, result expansion
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st);
+// block-diagonal level 0 of a batched Skeleton run: adjacency words of every row inside its block's column range, zeros
+// elsewhere, written to adj and adj0; also the level-1 degrees
+hipError_t launch_level0_batch(const float *C, unsigned long long *adj, unsigned long long *adj0, int *deg, int n, int words,
+                               const int2 *row_range, float th, hipStream_t st);
 hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int n, int words,
-                           int *wpre, const LevelCounters *cnt, hipStream_t st);
+                           int *wpre, const LevelCounters *cnt, const int2 *row_range, hipStream_t st);
 // The level's plan from the degrees alone: CSR offsets, the work items of every degree class (written straight into the
 // class buffers), totals, and the level's gate.  cnt = counters of level L; prev = counters of level L-1 (nullptr at
 // level 1) with its recheck-queue capacity; gate / seq: pinned host record of the level; sym: level 0's asymmetry flag
@@ -301,6 +310,10 @@ hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStre
 hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, const void *meta, bool count_removed, hipStream_t st);
 hipError_t launch_pair(int mode, const SweepParams &p, size_t lds, hipStream_t st);
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st);
+hipError_t launch_gather_rows(const float *M, int n, const int *idx, const int *row_src, const int *row_k, const long long *row_first,
+                              const long long *row_out, long long nrows, float *out, hipStream_t st);
+hipError_t launch_pack_block_bits(const unsigned long long *adj, int n, int words, const int2 *row_range, const int *row_blk,
+                                  const long long *blk_woff, unsigned long long *out, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);
 hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,
                               int n, int words, const int *x, const int *y, const float *z, long long nrec, hipStream_t st);

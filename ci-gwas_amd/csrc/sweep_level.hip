@@ -315,6 +315,72 @@ hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, un
     return hipGetLastError();
 }
 
+// Block-diagonal level 0 (batched runs: many small LD blocks along the diagonal of one allocation, bases multiples of 64,
+// so no bitmap word straddles two blocks).  One wave per row: the words of the row's own block come from C[row, lo..hi)
+// (coalesced 256-byte pieces, ballots = bitmap words), every other word of the row is zero -- the cross-block pairs do not
+// exist.  The verdict is cal_Indepl0's (cuPC-S.cu:458-484) evaluated per ordered pair; the reference evaluates i < j and
+// mirrors, which is the same thing on a bitwise symmetric matrix (the batched correlation build and the device gather of
+// a symmetric matrix write both triangles from one value).  Writes the live bitmap, its level-0 copy and the degrees.
+__global__ void __launch_bounds__(256) level0_batch_kernel(const float *__restrict__ C, unsigned long long *adj,
+                                                            unsigned long long *adj0, int *deg, int n, int words,
+                                                            const int2 *__restrict__ row_range, float th, float c_lo, float c_hi)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int2 rg = row_range[row];
+    const int w_lo = rg.x >> 6, w_hi = (rg.y + 63) >> 6;  // empty range: w_lo >= w_hi
+    unsigned long long *arow = adj + (size_t)row * words, *arow0 = adj0 ? adj0 + (size_t)row * words : nullptr;
+    for (int w = lane; w < words; w += 64)
+        if (w < w_lo || w >= w_hi || rg.y <= rg.x)
+        {
+            arow[w] = 0ull;
+            if (arow0) arow0[w] = 0ull;
+        }
+    int d = 0;
+    if (rg.y > rg.x)
+    {
+        const float *crow = C + (size_t)row * n;
+        for (int w = w_lo; w < w_hi; w++)
+        {
+            const int col = w * 64 + lane;
+            const bool valid = col < rg.y && col != row;
+            const float c = crow[valid ? col : row];
+            const float ac = fabsf(c);
+            bool rm;
+            if (ac < c_lo)
+                rm = true;
+            else if (ac > c_hi && ac <= 1.0f)
+                rm = false;
+            else
+                rm = z_below<false>(c, th);
+            const unsigned long long m = __ballot(valid && !rm);
+            if (lane == 0)
+            {
+                arow[w] = m;
+                if (arow0) arow0[w] = m;
+            }
+            d += __popcll(m);
+        }
+    }
+    if (lane == 0) deg[row] = d;
+}
+
+hipError_t launch_level0_batch(const float *C, unsigned long long *adj, unsigned long long *adj0, int *deg, int n, int words,
+                               const int2 *row_range, float th, hipStream_t st)
+{
+    float c_lo = 0.0f, c_hi = 2.0f;
+    if (th >= kThMinFilter)
+    {
+        const double tq = std::tanh((double)th);
+        c_lo = (float)(tq * (1.0 - 5e-4));
+        c_hi = (float)(tq * (1.0 + 5e-4));
+    }
+    hipLaunchKernelGGL(level0_batch_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, C, adj, adj0, deg, n, words, row_range,
+                       th, c_lo, c_hi);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------
 // compaction: bitmap -> CSR neighbour lists + work list
 // ---------------------------------------------------------------------------
@@ -338,17 +404,26 @@ hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int wor
 
 // one wave per row: ascending neighbour indices, reset of the row's selection state
 __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, const int *__restrict__ off, int *nbr,
-                                unsigned long long *best, int n, int words, int *wpre, const LevelCounters *cnt)
+                                unsigned long long *best, int n, int words, int *wpre, const LevelCounters *cnt,
+                                const int2 *__restrict__ row_range)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n || !cnt->active) return;
     const int o0 = off[row];
     int run = 0;
-    for (int w0 = 0; w0 < words; w0 += 64)
+    // batched runs: only the words of the row's own block can hold neighbours
+    int w_begin = 0, w_end = words;
+    if (row_range)
+    {
+        const int2 rg = row_range[row];
+        w_begin = rg.x >> 6;
+        w_end = (rg.y > rg.x) ? ((rg.y + 63) >> 6) : w_begin;
+    }
+    for (int w0 = w_begin; w0 < w_end; w0 += 64)
     {
         const int w = w0 + lane;
-        unsigned long long bits = (w < words) ? adj[(size_t)row * words + w] : 0ull;
+        unsigned long long bits = (w < w_end) ? adj[(size_t)row * words + w] : 0ull;
         const int c = __popcll(bits);
         int incl = c;
         for (int o = 1; o < 64; o <<= 1)
@@ -359,7 +434,7 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
         int pos = o0 + run + incl - c;
         // list position of the word's first neighbour: lets anyone turn (row, column) into a list position with
         // one more popcount (level1_prep_kernel)
-        if (wpre && w < words) wpre[(size_t)row * words + w] = run + incl - c;
+        if (wpre && w < w_end) wpre[(size_t)row * words + w] = run + incl - c;
         while (bits)
         {
             const int b = __ffsll((long long)bits) - 1;
@@ -372,9 +447,9 @@ __global__ void fill_nbr_kernel(const unsigned long long *__restrict__ adj, cons
 }
 
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int n, int words,
-                           int *wpre, const LevelCounters *cnt, hipStream_t st)
+                           int *wpre, const LevelCounters *cnt, const int2 *row_range, hipStream_t st)
 {
-    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, n, words, wpre, cnt);
+    hipLaunchKernelGGL(fill_nbr_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, off, nbr, best, n, words, wpre, cnt, row_range);
     return hipGetLastError();
 }
 
@@ -1297,12 +1372,22 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
         // 16-byte aligned LDS addresses whatever n is.  Only columns >= ya are ever asked for (yb follows ya in an
         // ascending list; idle lanes ask for ya itself).  The rounded-down head and rounded-up tail read at most three
         // elements of the neighbouring rows (ya >= 1 whenever the head reaches back, ya <= n - 2 always).
+        // Batched runs stage the columns of the row's own block only, [ya, hi), at LDS index column - lo + sh0 (lo, the
+        // block's base, is a multiple of 64 and keeps the alignment).
         const size_t g0 = (size_t)ya * n;
-        sh = (int)(g0 & 3);
-        const float *gbase = p.C + (g0 - sh);  // 16-byte aligned (p.C is: checked by the launcher)
-        const int i_end = n + sh;
+        const int sh0 = (int)(g0 & 3);
+        int lo = 0, hi = n;
+        if (p.row_range)
+        {
+            const int2 rg = p.row_range[ya];
+            lo = rg.x;
+            hi = rg.y;
+        }
+        sh = sh0 - lo;
+        const float *gbase = p.C + (g0 - sh0) + lo;  // 16-byte aligned (p.C is: checked by the launcher)
+        const int i_end = hi - lo + sh0;
         constexpr int kU = 4;
-        for (int i = ((ya + sh) & ~3) + tid * 4; i < i_end; i += THREADS * 4 * kU)
+        for (int i = ((ya - lo + sh0) & ~3) + tid * 4; i < i_end; i += THREADS * 4 * kU)
         {
             float4 v[kU];
 #pragma unroll
@@ -1688,7 +1773,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     // 93 VGPRs), the smaller one on a tie; when two rows do not fit (n > ~16,000) or the matrix is not 16-byte aligned
     // the row is gathered through L1/L2.  exp bit 32 forces the gather form, bits 64 / 128 / 256
     // force 512 / 1024 / 256 threads.
-    const size_t row_lds = sizeof(float) * ((size_t)n + 8);
+    const size_t row_lds = sizeof(float) * ((size_t)(p.row_range ? p.max_span : n) + 8);
     constexpr size_t kLdsCu = 160 * 1024;
     int threads = 0;
     if (two && !(exp & 32) && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)
@@ -1847,6 +1932,54 @@ __global__ void gather_sub_kernel(const float *__restrict__ M, int n, const int 
 hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float *out, hipStream_t st)
 {
     hipLaunchKernelGGL(gather_sub_kernel, dim3((k + 255) / 256, k), dim3(256), 0, st, M, n, idx, k, out);
+    return hipGetLastError();
+}
+
+// many sub-matrices in one launch (cusk_gather_rows): one wave per output row
+__global__ void __launch_bounds__(256) gather_rows_kernel(const float *__restrict__ M, int n, const int *__restrict__ idx,
+                                                           const int *__restrict__ row_src, const int *__restrict__ row_k,
+                                                           const long long *__restrict__ row_first,
+                                                           const long long *__restrict__ row_out, long long nrows, float *out)
+{
+    const long long t = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (t >= nrows) return;
+    const float *src = M + (size_t)row_src[t] * n;
+    const int k = row_k[t];
+    const int *cols = idx + row_first[t];
+    float *dst = out + row_out[t];
+    for (int c = lane; c < k; c += 64) dst[c] = src[cols[c]];
+}
+
+hipError_t launch_gather_rows(const float *M, int n, const int *idx, const int *row_src, const int *row_k, const long long *row_first,
+                              const long long *row_out, long long nrows, float *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((nrows + 3) / 4)), dim3(256), 0, st, M, n, idx, row_src, row_k, row_first,
+                       row_out, nrows, out);
+    return hipGetLastError();
+}
+
+// batched runs: the bitmap rows of every block, cut to the block's own words, packed back to back
+__global__ void __launch_bounds__(256) pack_block_bits_kernel(const unsigned long long *__restrict__ adj, int n, int words,
+                                                               const int2 *__restrict__ row_range, const int *__restrict__ row_blk,
+                                                               const long long *__restrict__ blk_woff, unsigned long long *out)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const int b = row_blk[row];
+    if (b < 0) return;
+    const int2 rg = row_range[row];
+    const int wb = (rg.y - rg.x + 63) >> 6, w0 = rg.x >> 6;
+    unsigned long long *dst = out + blk_woff[b] + (long long)(row - rg.x) * wb;
+    for (int w = lane; w < wb; w += 64) dst[w] = adj[(size_t)row * words + w0 + w];
+}
+
+hipError_t launch_pack_block_bits(const unsigned long long *adj, int n, int words, const int2 *row_range, const int *row_blk,
+                                  const long long *blk_woff, unsigned long long *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(pack_block_bits_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, adj, n, words, row_range, row_blk,
+                       blk_woff, out);
     return hipGetLastError();
 }
 

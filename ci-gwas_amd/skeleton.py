@@ -198,6 +198,45 @@ class Engine:
         self._check(lib().cusk_run_skeleton(self.h, C_dev, n, _ptr(Th), int(maxlevel), C.byref(st)))
         return Stats.of(st)
 
+    def run_skeleton_batch(self, C_dev: int, n: int, lo, hi, Th, maxlevel: int) -> Stats:
+        """cusk_run_skeleton_batch: blocks [lo[b], hi[b]) on the diagonal of one n x n allocation, swept in one run"""
+        Th = np.ascontiguousarray(Th, np.float32)
+        lo = np.ascontiguousarray(lo, np.int32)
+        hi = np.ascontiguousarray(hi, np.int32)
+        st = CuskStats()
+        self._check(lib().cusk_run_skeleton_batch(self.h, C_dev, int(n), len(lo), _ptr(lo), _ptr(hi), _ptr(Th), int(maxlevel),
+                                                  C.byref(st)))
+        self._batch = (lo.copy(), hi.copy())
+        return Stats.of(st)
+
+    def adjacency_blocks(self) -> list:
+        """per block of the last batched run its k x k int32 adjacency (cusk_result_adj_bits_blocks)"""
+        lo, hi = self._batch
+        k = (hi - lo).astype(np.int64)
+        wb = (k + 63) // 64
+        out = np.zeros(int((k * wb).sum()), np.uint64)
+        self._check(lib().cusk_result_adj_bits_blocks(self.h, _ptr(out)))
+        res, o = [], 0
+        for kb, w in zip(k, wb):
+            bits = out[o:o + kb * w].reshape(kb, w)
+            o += kb * w
+            G = np.unpackbits(bits.view(np.uint8), axis=1, bitorder="little")[:, :kb].astype(np.int32)
+            res.append(G)
+        return res
+
+    def gather_rows(self, M_dev: int, n: int, idx, row_src, row_k, row_first, row_out, out_dev: int | None = None,
+                    out_count: int = 0):
+        idx = np.ascontiguousarray(idx, np.int32)
+        row_src = np.ascontiguousarray(row_src, np.int32)
+        row_k = np.ascontiguousarray(row_k, np.int32)
+        row_first = np.ascontiguousarray(row_first, np.int64)
+        row_out = np.ascontiguousarray(row_out, np.int64)
+        host = None if out_dev is not None else np.zeros(int(out_count), np.float32)
+        self._check(lib().cusk_gather_rows(self.h, M_dev, int(n), _ptr(idx), len(idx), _ptr(row_src), _ptr(row_k), _ptr(row_first),
+                                           _ptr(row_out), len(row_src), out_dev if out_dev is not None else _ptr(host),
+                                           int(out_count), 1 if out_dev is not None else 0))
+        return host
+
     def run_hetcor(self, C_dev: int, n: int, th: float, maxlevel: int, N_dev: int | None = None,
                    ess_uniform: float = 0.0, G_init_dev: int | None = None, time_index=None) -> Stats:
         ti = np.ascontiguousarray(time_index, np.int32) if time_index is not None else None

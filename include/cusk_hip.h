@@ -125,7 +125,7 @@ const char *cusk_last_error(const cusk_engine *e);
  * classes and the winners' exact z run on an auxiliary stream), "corr_fp4" (default 1: the SNP x SNP contingency GEMMs of
  * cusk_corr_build on the FP4 matrix pipe; 0: the int8 MFMA form), "corr_popcount" (default 0; 1: bit-plane AND/popcount
  * cross-check kernels instead of the matrix cores), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
- * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (HIP events for cusk_stats: 0 total_ms only; 1, the default, around every level's sweep: kernel_ms, and level_ms = end of the previous level's sweep to the end of this one's; 2 also level start / end: level_ms = plan to finaliser; 3 only the pair around the level-1 row kernel: main_kernel_ms[1] -- every event costs a few microseconds of device time), "chunk0" (conditioning sets per work item of the first degree class, default 512), "tmaj_min_level" (first level swept by unions T = S + Y, one inverse per l + 1 tests: default 6, 99 = never; single threshold and symmetric matrix only), "tmaj_validate_stride" (with "validate": the union-major sweep checks the unions whose per-lane count is a multiple of this power of two against double precision; default 1 = all), "hostprof" (1: host-side phase marks of every run on stderr), "max_staged_classes" (test hook: at most this many degree classes keep their sub-matrix in LDS; 0 sends every row through the kernels of the unstaged class), "chunk0_low" (work-item size of the first degree class at levels 2-4, default 256), "vec_threads" (workgroup size of the vectorised sweep for the first degree class: 64, 128 or 256; default 64), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 1; every kernel checks its level's gate on the device), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
+ * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (HIP events for cusk_stats: 0 total_ms only; 1, the default, around every level's sweep: kernel_ms, and level_ms = end of the previous level's sweep to the end of this one's; 2 also level start / end: level_ms = plan to finaliser; 3 only the pair around the level-1 row kernel: main_kernel_ms[1] -- every event costs a few microseconds of device time), "chunk0" (conditioning sets per work item of the first degree class, default 512), "tmaj_min_level" (first level swept by unions T = S + Y, one inverse per l + 1 tests: default 6, 99 = never; single threshold and symmetric matrix only), "tmaj_validate_stride" (with "validate": the union-major sweep checks the unions whose per-lane count is a multiple of this power of two against double precision; default 1 = all), "hostprof" (1: host-side phase marks of every run on stderr), "max_staged_classes" (test hook: at most this many degree classes keep their sub-matrix in LDS; 0 sends every row through the kernels of the unstaged class), "chunk0_low" (work-item size of the first degree class at levels 2-4, default 256), "vec_threads" (workgroup size of the vectorised sweep for the first degree class: 64, 128 or 256; default 64), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
  * cusk_sepselect_greedy for candidate lists too long for LDS, default 4 GiB; such pairs run in batches of what fits). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
@@ -168,6 +168,31 @@ int cusk_run_hetcor(cusk_engine *e, const float *C_dev, const float *N_dev, floa
                     const int *G_init_dev, int n, float th, int maxlevel, const int *time_index,
                     cusk_stats *stats);
 
+/* Batched Skeleton run: `nblk` independent blocks (the LD blocks of one GPU's share of a chromosome job, or their reduced
+ * stage-two sets) swept in ONE run.  The reference has no counterpart: it runs one block per process (src/cli.cpp:507-512,
+ * README.md:62); per block the result is that of cusk_run_skeleton on the block alone (adjacency, separating sets).
+ * Layout: the blocks lie along the diagonal of one n x n allocation C_dev (leading dimension n): block b holds the
+ * variables [lo[b], hi[b]), its matrix at C_dev[i * n + j] for i, j in that range, each bitwise symmetric (what
+ * cusk_corr_build_batch and cusk_gather_rows write); lo[b] are ascending multiples of 64, the ranges disjoint; variables
+ * outside every range are padding and elements outside the diagonal blocks are never read (they need not be initialised).
+ * Th / maxlevel as cusk_run_skeleton (one threshold array: the blocks share the sample size).  stats are those of the
+ * whole batch; `level` is the last level at which ANY block still had a row with more neighbours than the level (a block
+ * that ends earlier has no test left at the later levels, so its result does not depend on the others).  Results:
+ * cusk_result_adj_bits_blocks, cusk_result_sepsets (x, y and set members are variable indices of the batch). */
+int cusk_run_skeleton_batch(cusk_engine *e, const float *C_dev, int n, int nblk, const int *lo, const int *hi,
+                            const float *Th, int maxlevel, cusk_stats *stats);
+/* adjacency of the last batched run, block by block: rows lo..hi-1 of block b, each cut to the (hi - lo + 63) / 64
+ * words of the block's own columns (bit j of a row = local variable j), blocks back to back.  out_host: room for
+ * sum_b (hi[b] - lo[b]) * ((hi[b] - lo[b] + 63) / 64) words. */
+int cusk_result_adj_bits_blocks(cusk_engine *e, uint64_t *out_host);
+/* Many sub-matrices in one launch: out[row_out[t] + c] = M_dev[row_src[t] * n + idx[row_first[t] + c]] for c < row_k[t],
+ * t < nrows (parent_set.cpp:84-238 for a batch: the stage-two matrices straight onto the diagonal of the next batch
+ * allocation, out_on_device = 1; the retained sub-matrices of the results, out_on_device = 0, out_count floats).  Index
+ * arrays are host memory. */
+int cusk_gather_rows(cusk_engine *e, const float *M_dev, int n, const int *idx_host, long long nidx, const int *row_src,
+                     const int *row_k, const long long *row_first, const long long *row_out, long long nrows, float *out,
+                     long long out_count, int out_on_device);
+
 /* Results of the last run (valid until the next run / destroy). */
 int cusk_result_n(const cusk_engine *e);
 /* adjacency bitmap on the device: n rows of cusk_result_words() uint64 words, bit j of row i */
@@ -198,6 +223,23 @@ int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen,
 int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N, size_t p,
                           const float *mean_dev, const float *std_dev, float *C_dev);
 int cusk_corr_build_end(cusk_engine *e, float *mxp_host);
+/* The correlation matrices of MANY LD blocks in one set of launches, written onto the diagonal of the n x n batch
+ * allocation C_dev that cusk_run_skeleton_batch sweeps (cli.cpp:543-649 once per block in the reference).  Inputs are the
+ * device-resident arrays of cusk_blockset_stage: bed_dev = marker 0 of the file set (ceil(N/4) bytes per marker),
+ * mean_dev / std_dev indexed by global marker, phen_dev column-major p x N.  Block b = markers first_marker[b] ..
+ * first_marker[b] + markers[b] - 1, variables base[b] .. base[b] + markers[b] + p - 1 of the allocation (markers, then the
+ * p traits; base[b] a multiple of 64).  Host arrays of nblk entries.
+ *   _mxp : marker x trait correlations of every block, into C_dev (both triangles) and, block after block, into the host
+ *          array mxp_host (sum markers[b] x p floats, row-major) for the prefilter (cli.cpp:561-576); returns when they
+ *          are there.
+ *   _mxm : marker x marker (Kendall-npn on the FP4 matrix pipe), trait x trait and the unit diagonal of the blocks with
+ *          keep[b] != 0 (keep = NULL: all); asynchronous on the engine's stream. */
+int cusk_corr_build_batch_mxp(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                              const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                              const int *markers, const int *base, int n, float *C_dev, float *mxp_host);
+int cusk_corr_build_batch_mxm(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                              const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                              const int *markers, const int *base, const unsigned char *keep, int n, float *C_dev);
 /* timing of the last cusk_corr_build: [0] decode, [1] count GEMM, [2] mxp/pxp, [3] total (ms) */
 void cusk_corr_timing(const cusk_engine *e, float *ms4);
 

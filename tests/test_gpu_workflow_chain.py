@@ -189,10 +189,12 @@ def test_workflow_chain(chain, oracle, tmp_path):
     expc = tmp_path / "cuskss_oracle"
     expc.mkdir()
     oracle.write_reduced(red, str(expc / "cuskss_merged"), with_sep=False)
-    for ext in (".mdim", ".ixs", ".adj", ".corr"):
+    # (the CLI's post-step has already replaced the raw .ixs -- positions in the selected-marker list -- by global marker
+    # indices, merge_blocks.py:322-324; the raw one is what the rewritten one is computed from, checked below)
+    for ext in (".mdim", ".adj", ".corr"):
         _same(str(cm / "cuskss_merged") + ext, str(expc / "cuskss_merged") + ext)
-    # ... and the post-step that rewrites it in the merged sparse format (ci-gwas.py:452-456); the oracle reads the
-    # product's dense files of this hop
+    # ... and the post-step that rewrites it in the merged sparse format (ci-gwas.py:452-456), from the oracle's dense
+    # files (identical to the product's, just compared)
     raw = tmp_path / "cuskss_raw"
     raw.mkdir()
     for ext in (".mdim", ".adj", ".corr"):
