@@ -36,6 +36,26 @@ class CuskStats(C.Structure):
     ]
 
 
+class CuskBatchStats(C.Structure):
+    """cusk_batch_stats of include/cusk_hip.h"""
+    _fields_ = [
+        ("blocks", C.c_int),
+        ("skipped", C.c_int),
+        ("markers", C.c_longlong),
+        ("retained", C.c_longlong),
+        ("vars_stage1", C.c_longlong),
+        ("vars_stage2", C.c_longlong),
+        ("tests", C.c_longlong * 2),
+        ("canonical", C.c_longlong * 2),
+        ("ms_corr", C.c_double),
+        ("ms_stage1", C.c_double),
+        ("ms_prune", C.c_double),
+        ("ms_stage2", C.c_double),
+        ("ms_reduce", C.c_double),
+        ("stage", CuskStats * 2),
+    ]
+
+
 class CuskBlockStats(C.Structure):
     """cusk_block_stats of include/cusk_hip.h"""
     _fields_ = [
@@ -106,6 +126,17 @@ SYMBOLS = {
     "cusk_blockset_run_block": (_i, [_vp, _vp, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
     "cusk_blockset_run_block_next": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp), C.POINTER(CuskBlockStats)]),
     "cusk_blockset_last_error": (C.c_char_p, []),
+    "cusk_blockset_release_engine": (None, [_vp, _vp]),
+    "cusk_blockset_run_batch": (_i, [_vp, _vp, _vp, _i, C.POINTER(_vp), _vp]),
+    "cusk_batch_result_count": (_i, [_vp]),
+    "cusk_batch_result_block_index": (_i, [_vp, _i]),
+    "cusk_batch_result_block": (_vp, [_vp, _i]),
+    "cusk_batch_result_write": (_i, [_vp, C.c_char_p]),
+    "cusk_batch_result_packed_bytes": (_sz, [_vp]),
+    "cusk_batch_result_pack": (_i, [_vp, _vp, _sz]),
+    "cusk_packed_results_write": (_i, [_vp, _sz, C.c_char_p, _vp]),
+    "cusk_batch_result_free": (None, [_vp]),
+    "cusk_corr_build_pending": (_i, [_vp]),
     "cusk_block_result_dims": (None, [_vp, C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),
     "cusk_block_result_stem": (C.c_char_p, [_vp]),
     "cusk_block_result_ixs": (_vp, [_vp]),

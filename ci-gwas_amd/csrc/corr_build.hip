@@ -1424,6 +1424,8 @@ extern "C" int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_de
     return rc;
 }
 
+extern "C" int cusk_corr_build_pending(const cusk_engine *e) { return (e && e->mxp_pending) ? 1 : 0; }
+
 extern "C" int cusk_corr_build_end(cusk_engine *e, float *mxp_host)
 {
     if (!e) return CUSK_ERR_ARG;

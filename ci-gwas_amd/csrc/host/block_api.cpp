@@ -3,7 +3,7 @@
 #include <map>
 #include <mutex>
 
-#include "block_pipeline.h"
+#include "batch_pipeline.h"
 
 using namespace host;
 
@@ -30,7 +30,24 @@ struct cusk_blockset
         std::lock_guard<std::mutex> lock(mu);
         auto &s = scratch[e];
         if (!s) s.reset(new BlockScratch());
+        // an entry left behind by an engine that was destroyed while a build was pending (a new engine can get the same
+        // address): the engine itself knows whether a build is in flight
+        if (s->pending >= 0 && !cusk_corr_build_pending(e)) s->pending = -1;
         return *s;
+    }
+    std::map<cusk_engine *, std::unique_ptr<BatchScratch>> batch_scratch;
+    BatchScratch &batch_scratch_of(cusk_engine *e)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        auto &s = batch_scratch[e];
+        if (!s) s.reset(new BatchScratch());
+        return *s;
+    }
+    void release_engine(cusk_engine *e)
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        scratch.erase(e);
+        batch_scratch.erase(e);
     }
 };
 
@@ -185,6 +202,189 @@ extern "C" int cusk_blockset_run_block_next(cusk_blockset *bs, cusk_engine *e, i
 }
 
 extern "C" const char *cusk_blockset_last_error(void) { return g_err.c_str(); }
+
+extern "C" void cusk_blockset_release_engine(cusk_blockset *bs, cusk_engine *e)
+{
+    if (!bs || !e) return;
+    if (cusk_corr_build_pending(e)) (void)cusk_corr_build_end(e, nullptr);  // nothing may still write into the scratch
+    (void)cusk_engine_bind_thread(e);
+    bs->release_engine(e);
+}
+
+// ---- many blocks per device run (host/batch_pipeline.h) ----
+struct cusk_batch_result
+{
+    std::vector<cusk_block_result> blocks;
+    std::vector<int> index;
+};
+
+extern "C" int cusk_blockset_run_batch(cusk_blockset *bs, cusk_engine *e, const int *block_indices, int nblocks,
+                                       cusk_batch_result **out, cusk_batch_stats *stats)
+{
+    if (!bs || !e || !out || !block_indices || nblocks < 0) return CUSK_ERR_ARG;
+    *out = nullptr;
+    if (!bs->staged_of(e) && cusk_blockset_stage(bs, e) != CUSK_OK) return CUSK_ERR_HIP;
+    const StagedInputs *staged = bs->staged_of(e);
+    BatchScratch &scratch = bs->batch_scratch_of(e);
+    std::unique_ptr<cusk_batch_result> res(new cusk_batch_result());
+    try
+    {
+        std::vector<BatchBlockOut> outs;
+        BatchStats st;
+        run_cusk_batch(e, bs->in, *staged, std::vector<int>(block_indices, block_indices + nblocks), scratch, outs, st);
+        for (BatchBlockOut &o : outs)
+        {
+            if (o.skipped) continue;
+            res->blocks.emplace_back();
+            res->blocks.back().r = std::move(o.r);
+            res->blocks.back().stem = std::move(o.stem);
+            res->index.push_back(o.block_index);
+        }
+        if (stats)
+        {
+            stats->blocks = st.blocks;
+            stats->skipped = st.skipped;
+            stats->markers = st.markers;
+            stats->retained = st.retained;
+            stats->vars_stage1 = st.vars_stage1;
+            stats->vars_stage2 = st.vars_stage2;
+            for (int k = 0; k < 2; k++)
+            {
+                stats->tests[k] = st.tests[k];
+                stats->canonical[k] = st.canonical[k];
+                stats->stage[k] = st.stage[k];
+            }
+            stats->ms_corr = st.ms_corr;
+            stats->ms_stage1 = st.ms_stage1;
+            stats->ms_prune = st.ms_prune;
+            stats->ms_stage2 = st.ms_stage2;
+            stats->ms_reduce = st.ms_reduce;
+        }
+        *out = res.release();
+    }
+    catch (const EngineError &ex)
+    {
+        copy_err(ex.what(), nullptr, 0);
+        return CUSK_ERR_HIP;
+    }
+    catch (const std::exception &ex)
+    {
+        copy_err(ex.what(), nullptr, 0);
+        return CUSK_ERR_ARG;
+    }
+    return CUSK_OK;
+}
+
+extern "C" int cusk_batch_result_count(const cusk_batch_result *r) { return r ? (int)r->blocks.size() : 0; }
+extern "C" int cusk_batch_result_block_index(const cusk_batch_result *r, int i)
+{
+    return (r && i >= 0 && (size_t)i < r->index.size()) ? r->index[(size_t)i] : -1;
+}
+extern "C" const cusk_block_result *cusk_batch_result_block(const cusk_batch_result *r, int i)
+{
+    return (r && i >= 0 && (size_t)i < r->blocks.size()) ? &r->blocks[(size_t)i] : nullptr;
+}
+extern "C" void cusk_batch_result_free(cusk_batch_result *r) { delete r; }
+
+extern "C" int cusk_batch_result_write(const cusk_batch_result *r, const char *outdir)
+{
+    if (!r || !outdir) return CUSK_ERR_ARG;
+    try
+    {
+        check_path(outdir);
+        for (const cusk_block_result &b : r->blocks) write_reduced(b.r, make_path(outdir, b.stem, ""), true);
+    }
+    catch (const std::exception &ex)
+    {
+        copy_err(ex.what(), nullptr, 0);
+        return CUSK_ERR_ARG;
+    }
+    return CUSK_OK;
+}
+
+static size_t packed_bytes_of(const cusk_block_result &b)
+{
+    const size_t k = b.r.num_var;
+    return 24 + b.stem.size() + 4 * (k + 2 * k * k + k * k * b.r.max_level);
+}
+
+extern "C" size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r)
+{
+    size_t t = 0;
+    if (r)
+        for (const cusk_block_result &b : r->blocks) t += packed_bytes_of(b);
+    return t;
+}
+
+extern "C" int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes)
+{
+    if (!r || (!buf && bytes)) return CUSK_ERR_ARG;
+    if (bytes < cusk_batch_result_packed_bytes(r)) return CUSK_ERR_ARG;
+    char *p = static_cast<char *>(buf);
+    for (size_t i = 0; i < r->blocks.size(); i++)
+    {
+        const cusk_block_result &b = r->blocks[i];
+        const int head[6] = {r->index[i], (int)b.r.num_var, (int)b.r.num_phen, (int)b.r.max_level, 1, (int)b.stem.size()};
+        std::memcpy(p, head, 24);
+        p += 24;
+        std::memcpy(p, b.stem.data(), b.stem.size());
+        p += b.stem.size();
+        auto put = [&](const void *src, size_t n) {
+            std::memcpy(p, src, n);
+            p += n;
+        };
+        put(b.r.new_to_old.data(), 4 * b.r.new_to_old.size());
+        put(b.r.G.data(), 4 * b.r.G.size());
+        put(b.r.C.data(), 4 * b.r.C.size());
+        put(b.r.S.data(), 4 * b.r.S.size());
+    }
+    return CUSK_OK;
+}
+
+extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const char *outdir, int *blocks_written)
+{
+    if ((!buf && bytes) || !outdir) return CUSK_ERR_ARG;
+    if (blocks_written) *blocks_written = 0;
+    try
+    {
+        check_path(outdir);
+        const char *p = static_cast<const char *>(buf), *end = p + bytes;
+        while (p < end)
+        {
+            if (end - p < 24) throw std::runtime_error("truncated packed results");
+            int head[6];
+            std::memcpy(head, p, 24);
+            p += 24;
+            const size_t k = (size_t)head[1], ml = (size_t)head[3], ns = (size_t)head[5];
+            const bool has_sep = head[4] != 0;
+            const size_t need = ns + 4 * (k + 2 * k * k + (has_sep ? k * k * ml : 0));
+            if ((size_t)(end - p) < need) throw std::runtime_error("truncated packed results");
+            Reduced r;
+            const std::string stem(p, ns);
+            p += ns;
+            r.num_var = k;
+            r.num_phen = (size_t)head[2];
+            r.max_level = ml;
+            auto take = [&](auto &vec, size_t n) {
+                vec.resize(n);
+                std::memcpy(vec.data(), p, 4 * n);
+                p += 4 * n;
+            };
+            take(r.new_to_old, k);
+            take(r.G, k * k);
+            take(r.C, k * k);
+            if (has_sep) take(r.S, k * k * ml);
+            write_reduced(r, make_path(outdir, stem, ""), has_sep);
+            if (blocks_written) (*blocks_written)++;
+        }
+    }
+    catch (const std::exception &ex)
+    {
+        copy_err(ex.what(), nullptr, 0);
+        return CUSK_ERR_ARG;
+    }
+    return CUSK_OK;
+}
 
 extern "C" void cusk_block_result_dims(const cusk_block_result *r, long long *num_var, long long *num_phen, long long *max_level)
 {

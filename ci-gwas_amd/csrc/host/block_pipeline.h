@@ -451,7 +451,7 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
     if (!in.full_corrmats_dir.empty())
     {  // cli.cpp:27,651-658 (compile-time switch WRITE_FULL_CORRMATS in the reference)
         std::vector<float> full(n * n);
-        cusk_dev_download(full.data(), scr.C.p, sizeof(float) * n * n);
+        if (cusk_dev_download(full.data(), scr.C.p, sizeof(float) * n * n) != CUSK_OK) engine_die("correlation matrix download", e);
         write_binary(make_path(in.full_corrmats_dir, stem, ".all_corrs"), full.data(), full.size());
     }
 

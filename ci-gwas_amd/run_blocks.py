@@ -36,11 +36,11 @@ if __package__ in (None, ""):  # run as a script (torchrun): make `cigwas_amd` i
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import cigwas_amd  # noqa: F401
     from cigwas_amd import shard
-    from cigwas_amd._lib import CuskBlockStats, lib
+    from cigwas_amd._lib import CuskBatchStats, CuskBlockStats, lib
     from cigwas_amd.skeleton import Engine
 else:
     from . import shard
-    from ._lib import CuskBlockStats, lib
+    from ._lib import CuskBatchStats, CuskBlockStats, lib
     from .skeleton import Engine
 
 
@@ -63,6 +63,8 @@ class BlockSet:
     def close(self):
         for engines in getattr(self, "_engines", {}).values():
             for e in engines:
+                if self.h and e.h:
+                    lib().cusk_blockset_release_engine(self.h, e.h)
                 e.close()
         self._engines = {}
         if self.h:
@@ -84,6 +86,16 @@ class BlockSet:
 
     def costs(self) -> list[float]:
         return [shard.predicted_cost(self.markers(i), self.num_samples, self.num_phen) for i in range(self.num_blocks)]
+
+    def run_batch(self, eng: Engine, blocks):
+        """cusk_blockset_run_batch: every block of `blocks` in one set of device runs -> (BatchResult, CuskBatchStats)"""
+        ix = np.ascontiguousarray(blocks, np.int32)
+        res = C.c_void_p()
+        st = CuskBatchStats()
+        rc = lib().cusk_blockset_run_batch(self.h, eng.h, ix.ctypes.data_as(C.c_void_p), len(ix), C.byref(res), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"batch {list(blocks)[:4]}...: {lib().cusk_blockset_last_error().decode()}")
+        return BatchResult(res), st
 
     def run_block(self, eng: Engine, i: int, next_block: int = -1):
         """-> (shard.BlockResult | None if the block is skipped, CuskBlockStats).  next_block: the block this engine
@@ -116,6 +128,71 @@ class BlockSet:
         return br, st
 
 
+class BatchResult:
+    """cusk_batch_result of include/cusk_hip.h: the reduced results of the blocks of one batch, owned by the library"""
+
+    def __init__(self, handle):
+        self.h = handle
+        self.count = lib().cusk_batch_result_count(handle)
+        self.block_indices = [lib().cusk_batch_result_block_index(handle, i) for i in range(self.count)]
+
+    def write(self, outdir: str) -> None:
+        if lib().cusk_batch_result_write(self.h, outdir.encode()) != 0:
+            raise RuntimeError(f"writing batch results: {lib().cusk_blockset_last_error().decode()}")
+
+    def pack(self) -> np.ndarray:
+        """the results as one byte string (shard.BlockResult.pack layout, block after block)"""
+        nbytes = int(lib().cusk_batch_result_packed_bytes(self.h))
+        buf = np.zeros(nbytes, np.uint8)
+        if nbytes and lib().cusk_batch_result_pack(self.h, buf.ctypes.data_as(C.c_void_p), nbytes) != 0:
+            raise RuntimeError("cusk_batch_result_pack failed")
+        return buf
+
+    def results(self) -> list:
+        buf, pos, out = self.pack(), 0, []
+        while pos < buf.size:
+            r, pos = shard.BlockResult.unpack(buf, pos)
+            out.append(r)
+        return out
+
+    def free(self):
+        if self.h:
+            lib().cusk_batch_result_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def write_packed(buf: np.ndarray, outdir: str) -> int:
+    """cusk_packed_results_write: the files of every block in a packed byte string (rank 0 after the gather)"""
+    n = C.c_int(0)
+    buf = np.ascontiguousarray(buf, np.uint8)
+    if lib().cusk_packed_results_write(buf.ctypes.data_as(C.c_void_p), buf.size, outdir.encode(), C.byref(n)) != 0:
+        raise RuntimeError(f"writing gathered results: {lib().cusk_blockset_last_error().decode()}")
+    return int(n.value)
+
+
+def make_batches(blocks: list[int], sizes: dict, num_phen: int, batch_vars: int) -> list[list[int]]:
+    """Consecutive blocks of `blocks` whose padded variable counts -- (markers + traits) rounded up to 64 -- sum to at most
+    batch_vars (a single block larger than that is a batch of its own).  The batch's correlation matrix takes
+    4 x (that sum)^2 bytes of HBM; one level loop serves the whole batch."""
+    out, cur, tot = [], [], 0
+    for b in blocks:
+        v = (sizes[b] + num_phen + 63) // 64 * 64
+        if cur and tot + v > batch_vars:
+            out.append(cur)
+            cur, tot = [], 0
+        cur.append(b)
+        tot += v
+    if cur:
+        out.append(cur)
+    return out
+
+
 class _Queue:
     """Where a rank's workers get their next block from: the rank's own list (static assignment) or one counter
     shared by all ranks in the job's c10d store (dynamic: blocks are handed out in descending predicted cost)."""
@@ -140,6 +217,98 @@ class _Queue:
             return -1
         with self.lock:
             return self.order[self.pos] if self.pos < len(self.order) else -1
+
+
+def run_rank_batched(bs, queue: "_Queue", device: int, batch_vars: int, options: dict | None = None, write_dir: str | None = None):
+    """The rank's blocks in batches of at most `batch_vars` padded variables, each batch through cusk_blockset_run_batch
+    (one level loop per stage for the whole batch).  -> (list of BatchResult, list of CuskBatchStats).  write_dir: the
+    files of a batch are written (by the library, cusk_batch_result_write) on a thread of their own beside the next batch."""
+    cache = bs._engines.setdefault(device, [])
+    if not cache:
+        cache.append(Engine(device))
+    eng = cache[0]
+    for k, v in (options or {}).items():
+        if k != "corr_ahead":
+            eng.set_option(k, int(v))
+    if not bs.stage(eng):
+        raise RuntimeError("batched runs need the block set's inputs on the device (cusk_blockset_stage failed)")
+    def batches():
+        """batches drawn from the queue as they are needed (with the shared counter of the dynamic schedule a rank must not
+        take more than it is about to run); a block that does not fit the current batch opens the next one"""
+        carry = None
+        while True:
+            cur, tot = [], 0
+            while True:
+                b = carry if carry is not None else queue.next()
+                carry = None
+                if b is None:
+                    break
+                v = (bs.markers(b) + bs.num_phen + 63) // 64 * 64
+                if cur and tot + v > batch_vars:
+                    carry = b
+                    break
+                cur.append(b)
+                tot += v
+            if not cur:
+                return
+            yield cur
+
+    results, stats, errors = [], [], []
+    import queue as _q
+
+    wq = _q.Queue() if write_dir is not None else None
+
+    def writer():
+        while True:
+            r = wq.get()
+            if r is None:
+                return
+            try:
+                r.write(write_dir)
+            except Exception as exc:  # noqa: BLE001
+                errors.append(exc)
+
+    wt = threading.Thread(target=writer) if wq is not None else None
+    if wt is not None:
+        wt.start()
+    try:
+        for batch in batches():
+            if errors:
+                break
+            br, st = bs.run_batch(eng, batch)
+            results.append(br)
+            stats.append(st)
+            if wq is not None:
+                wq.put(br)
+    finally:
+        if wt is not None:
+            wq.put(None)
+            wt.join()
+    if errors:
+        raise errors[0]
+    return results, stats
+
+
+def gather_packed(payload: np.ndarray, device=None, group=None):
+    """every rank's packed results -> rank 0 (list of byte arrays, one per rank; None elsewhere): a size all_gather and
+    one padded all_gather -- RCCL when the group's backend is nccl -- as shard.gather_results"""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = device if device is not None else "cpu"
+    size = torch.tensor([payload.size], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, size, group=group)
+    cap = max(1, int(max(int(s.item()) for s in sizes)))
+    mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    if payload.size:
+        mine[: payload.size] = torch.from_numpy(payload).to(dev)
+    bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
+    dist.all_gather(bufs, mine, group=group)
+    if rank != 0:
+        return None
+    return [bufs[r][: int(sizes[r].item())].cpu().numpy() for r in range(world)]
 
 
 def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None,
@@ -226,7 +395,7 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
 
 def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: str = "lpt", collective_device=None,
             options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block",
-            stage: bool = True, writer: str = "rank0"):
+            stage: bool = True, writer: str = "rank0", batch_vars: int = 0, timings: dict | None = None):
     """One rank's part of the job (call on every rank of an initialised process group, or without one for a
     single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment).
 
@@ -248,6 +417,47 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
     else:
         owned = shard.assign_blocks(costs, world)[rank]
         queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
+    if batch_vars > 0 and engine_factory is None:
+        # batched execution: the rank's blocks in batches, one level loop per stage and batch.  Returns the block indices
+        # that were written (all of the job's on rank 0 with writer = rank0, the rank's own with writer = local), the
+        # per-batch stats, and the assignment
+        t0 = time.perf_counter()
+        bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer == "local" else None)
+        done = sorted(b for r in bres for b in r.block_indices)
+        t1 = time.perf_counter()
+        if writer == "local":
+            if distributed:
+                dist.barrier(group)
+        else:
+            payload = np.concatenate([r.pack() for r in bres]) if bres else np.zeros(0, np.uint8)
+            if distributed:
+                parts = gather_packed(payload, device=collective_device, group=group)
+            else:
+                parts = [payload]
+            t2 = time.perf_counter()
+            if timings is not None:
+                timings["gather_s"] = t2 - t1
+            if rank == 0:
+                done = []
+                for part in parts:
+                    pos = 0
+                    while pos < part.size:  # block indices of what arrived (headers only)
+                        head = part[pos:pos + 24].view(np.int32)
+                        bi, k, _nph, ml, has_sep, ns = (int(v) for v in head)
+                        done.append(bi)
+                        pos += 24 + ns + 4 * (k + 2 * k * k + (k * k * ml if has_sep else 0))
+                    if outdir is not None and part.size:
+                        write_packed(part, outdir)
+                done.sort()
+            else:
+                done = None
+            if timings is not None:
+                timings["write_s"] = time.perf_counter() - t2
+        if timings is not None:
+            timings["compute_s"] = t1 - t0
+        for r in bres:
+            r.free()
+        return done, bstats, (owned if owned is not None else None)
     results, stats = run_rank(bs, queue, device, inflight, options, engine_factory, stage,
                               write_dir=outdir if writer == "local" else None)
     if writer == "local":
@@ -279,6 +489,9 @@ def main(argv=None):
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
     ap.add_argument("--writer", choices=["rank0", "local"], default="rank0",
                     help="rank0: results gathered to rank 0, which writes every file; local: every rank writes the files of its own blocks")
+    ap.add_argument("--batch-vars", type=int, default=16384,
+                    help="blocks are run in batches of at most this many (padded) variables, one level loop per stage for the "
+                         "whole batch; 0: one block per engine run")
     ap.add_argument("--no-stage", action="store_true", help="do not keep the whole .bed in HBM; every block uploads its slice")
     ap.add_argument("--device", type=int, default=None, help="GPU of this rank (default LOCAL_RANK modulo the device count)")
     args = ap.parse_args(argv)
@@ -307,11 +520,17 @@ def main(argv=None):
     t_open = time.perf_counter() - t0
     # no per-level HIP events: nothing here reads the per-level kernel times, and every event costs the launch-bound
     # small blocks a few microseconds of device time
+    batch_vars = 0 if args.no_stage else max(0, args.batch_vars)
     allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage,
-                                 options={"timing": 0}, writer=args.writer)
+                                 options={"timing": 0}, writer=args.writer, batch_vars=batch_vars)
     dt = time.perf_counter() - t0
-    tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
-    print(f"[rank {rank}/{world}] gpu {device}: {len(stats)} blocks ({sum(1 for s in stats.values() if s.skipped)} skipped), "
+    if batch_vars > 0:
+        tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats)
+        nblk, nskip = sum(int(s.blocks) for s in stats), sum(int(s.skipped) for s in stats)
+    else:
+        tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats.values())
+        nblk, nskip = len(stats), sum(1 for s in stats.values() if s.skipped)
+    print(f"[rank {rank}/{world}] gpu {device}: {nblk} blocks ({nskip} skipped), "
           f"{tests:.3e} CI tests, open {t_open:.2f} s, total {dt:.2f} s", flush=True)
     if rank == 0 or args.writer == "local":
         print(f"[rank {rank}] wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}", flush=True)

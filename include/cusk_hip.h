@@ -223,6 +223,7 @@ int cusk_corr_build(cusk_engine *e, const unsigned char *bed, const float *phen,
 int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N, size_t p,
                           const float *mean_dev, const float *std_dev, float *C_dev);
 int cusk_corr_build_end(cusk_engine *e, float *mxp_host);
+int cusk_corr_build_pending(const cusk_engine *e); /* 1 while a cusk_corr_build_begin has not been ended */
 /* The correlation matrices of MANY LD blocks in one set of launches, written onto the diagonal of the n x n batch
  * allocation C_dev that cusk_run_skeleton_batch sweeps (cli.cpp:543-649 once per block in the reference).  Inputs are the
  * device-resident arrays of cusk_blockset_stage: bed_dev = marker 0 of the file set (ceil(N/4) bytes per marker),
@@ -334,6 +335,39 @@ int cusk_blockset_run_block(cusk_blockset *bs, cusk_engine *e, int block_index, 
 int cusk_blockset_run_block_next(cusk_blockset *bs, cusk_engine *e, int block_index, int next_index,
                                  cusk_block_result **out, cusk_block_stats *stats);
 const char *cusk_blockset_last_error(void);
+/* Forgets what the block set keeps for engine e -- its device scratch (block matrices) and the state of a correlation
+ * build started ahead -- and releases that memory.  Call before destroying an engine that ran blocks of this set when the
+ * set outlives it (cusk_blockset_close releases everything anyway). */
+void cusk_blockset_release_engine(cusk_blockset *bs, cusk_engine *e);
+
+/* MANY blocks in one set of device runs (host/batch_pipeline.h): the correlation matrices of all `nblocks` blocks are built
+ * by one set of launches, both skeleton stages sweep them in one level loop each (cusk_run_skeleton_batch), one read-out
+ * brings the reduced results back.  The reference runs one block per process (cli.cpp:507-512, README.md:62); per block
+ * the result -- and every file written from it -- is the one of cusk_blockset_run_block (= `mps cusk` on that block).
+ * Needs the inputs on e's device (cusk_blockset_stage; done here when it has not been).  The padded variable count of
+ * the batch, sum over blocks of (markers + traits) rounded up to 64, squared, times 4 bytes is the device memory of its
+ * matrix: the caller chooses the batches (ci-gwas_amd/run_blocks.py: --batch-vars).  stats may be NULL. */
+typedef struct cusk_batch_result cusk_batch_result;
+typedef struct cusk_batch_stats {
+    int blocks, skipped;                 /* blocks asked for / skipped by the prefilter (cli.cpp:561-576) */
+    long long markers, retained;         /* markers of all blocks / markers in the results */
+    long long vars_stage1, vars_stage2;  /* padded variable counts of the two batch allocations */
+    long long tests[2], canonical[2];    /* executed / canonical CI tests of stage one and two */
+    double ms_corr, ms_stage1, ms_prune, ms_stage2, ms_reduce; /* wall-clock phases of the batch */
+    cusk_stats stage[2];                 /* engine counters of both stages (whole batch) */
+} cusk_batch_stats;
+int cusk_blockset_run_batch(cusk_blockset *bs, cusk_engine *e, const int *block_indices, int nblocks,
+                            cusk_batch_result **out, cusk_batch_stats *stats);
+int cusk_batch_result_count(const cusk_batch_result *r);                       /* blocks with a result */
+int cusk_batch_result_block_index(const cusk_batch_result *r, int i);          /* index of result i in the .blocks file */
+const cusk_block_result *cusk_batch_result_block(const cusk_batch_result *r, int i); /* borrowed; accessors below */
+int cusk_batch_result_write(const cusk_batch_result *r, const char *outdir);   /* every block's five files */
+/* the results as one byte string (the multi-GPU job gathers these to rank 0): per block six int32 {block index, num_var,
+ * num_phen, max_level, 1, length of the stem} + stem + .ixs + .adj + .corr + .sep contents */
+size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r);
+int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes);
+int cusk_packed_results_write(const void *buf, size_t bytes, const char *outdir, int *blocks_written);
+void cusk_batch_result_free(cusk_batch_result *r);
 /* the reduced result of one block: what ReducedGCS::to_file writes (include/mps/parent_set.h:42-52) */
 void cusk_block_result_dims(const cusk_block_result *r, long long *num_var, long long *num_phen, long long *max_level);
 const char *cusk_block_result_stem(const cusk_block_result *r);

@@ -122,3 +122,100 @@ def test_gather_rows_places_submatrices(cg):
     assert np.array_equal(got, want)
     Md.free()
     e.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# block driver level: cusk_blockset_run_batch against per-block `mps cusk` (files byte-identical) and the oracle pipeline
+# ---------------------------------------------------------------------------------------------------------------------
+import os
+import socket
+import subprocess
+import sys
+
+from test_gpu_run_blocks import ALPHA, DEPTH, L1, L2, ROOT, _same_files, chromosome  # noqa: E402,F401  (the fixture)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("batch_vars,writer", [(100000, "local"), (1024, "rank0"), (600, "local")])
+def test_batched_driver_writes_the_files_of_per_block_mps_cusk(chromosome, tmp_path, batch_vars, writer):
+    """all 11 blocks in one batch, in several batches, and with batches of one block (every block above the budget)"""
+    from cigwas_amd import run_blocks as rb
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), int(DEPTH))
+    out = tmp_path / "out"
+    out.mkdir()
+    tm = {}
+    done, stats, owned = rb.run_job(bs, str(out), device=0, writer=writer, batch_vars=batch_vars, options={"timing": 0}, timings=tm)
+    files = _same_files(str(chromosome["ref"]), str(out))
+    assert len(files) == 5 * len(done) and owned == list(range(bs.num_blocks))
+    assert sum(s.blocks for s in stats) == bs.num_blocks and sum(s.skipped for s in stats) == bs.num_blocks - len(done) > 0
+    assert all(s.tests[0] > 0 for s in stats if s.blocks > s.skipped) and "compute_s" in tm
+    if batch_vars == 100000:
+        assert len(stats) == 1 and stats[0].vars_stage1 >= 2900 and stats[0].canonical[0] > 0 and stats[0].canonical[1] > 0
+    else:
+        assert len(stats) > 3
+    bs.close()
+
+
+def test_batch_result_accessors_and_oracle(chromosome, oracle, tmp_path):
+    """a batch's results through the pack / unpack path, two blocks against the oracle pipeline from the packed genotypes"""
+    from cigwas_amd import run_blocks as rb
+    from cigwas_amd.skeleton import Engine
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), int(DEPTH))
+    e = Engine(0)
+    sig = chromosome["signal"]
+    br, st = bs.run_batch(e, [sig[-1], 1, sig[0]])  # any order, a block without signal in between
+    res = {r.block_index: r for r in br.results()}
+    assert set(res) == {sig[0], sig[-1]} and st.skipped == 1 and br.block_indices == [sig[-1], sig[0]]
+    bed = np.fromfile(chromosome["stem"] + ".bed", np.uint8)[3:].reshape(-1, (chromosome["N"] + 3) // 4)
+    means = np.loadtxt(chromosome["stem"] + ".means", dtype=np.float32)
+    stds = np.loadtxt(chromosome["stem"] + ".stds", dtype=np.float32)
+    phen = oracle.load_phen(chromosome["phen"])[2]
+    N, p = chromosome["N"], chromosome["p"]
+    Th = oracle.threshold_array(N, float(ALPHA))
+    for b in (sig[0], sig[-1]):
+        cid, f, l, g0 = chromosome["bounds"][b]
+        mb = l - f + 1
+        sel = slice(g0, g0 + mb)
+        o_mxm, o_mxp, o_pxp = oracle.corr_pearson_npn(bed[sel], phen, mb, N, p, means[sel], stds[sel])
+        ref = oracle.cusk_from_corr(oracle.square_from_cusk_corrs(o_mxm, o_mxp, o_pxp, mb, p), p, Th, int(L1), int(L2), int(DEPTH))
+        r = res[b]
+        assert r.stem == f"{cid}_{f}_{l}" and r.max_level == 14 and r.num_phen == p
+        assert list(r.new_to_old) == list(ref.new_to_old)
+        assert np.array_equal(r.adj.reshape(-1), np.asarray(ref.G, np.int32).reshape(-1))
+        assert np.array_equal(r.sep.reshape(-1), np.asarray(ref.S, np.int32).reshape(-1))
+        assert np.allclose(r.corr.reshape(-1), np.asarray(ref.C, np.float32).reshape(-1), atol=1e-5, rtol=0)
+    # packed bytes -> files on "rank 0"
+    out = tmp_path / "o"
+    out.mkdir()
+    assert rb.write_packed(br.pack(), str(out)) == 2
+    for f in os.listdir(out):
+        assert open(out / f, "rb").read() == open(os.path.join(str(chromosome["ref"]), f), "rb").read()
+    br.free()
+    lib_release = rb.lib().cusk_blockset_release_engine
+    lib_release(bs.h, e.h)
+    e.close()
+    bs.close()
+
+
+@pytest.mark.timeout(900)
+def test_two_ranks_batched_over_gloo(chromosome, tmp_path):
+    """the job under torchrun, two ranks sharing the GPU, batched execution, results gathered to rank 0"""
+    out = tmp_path / "out"
+    out.mkdir()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "ci-gwas_amd", "run_blocks.py"), chromosome["phen"],
+           chromosome["stem"], chromosome["blocks"], ALPHA, L1, L2, DEPTH, str(out), "--backend", "gloo", "--batch-vars", "2048",
+           "--writer", "rank0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=800)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    _same_files(str(chromosome["ref"]), str(out))
