@@ -12,11 +12,17 @@ whole-chromosome pass through the multi-GPU block driver on this one GPU (`chrom
 
 N > 1 (torchrun, one rank per GPU): BASELINE.json config 4, the whole-chromosome run -- 25 unequal LD blocks per GPU
 (200 blocks x ~500 SNPs x 20 traits on 8 GPUs; weak scaling), written as a PLINK file set, every block through the
-product's block driver (ci-gwas_amd/run_blocks.py: `cusk_blockset_*`, longest-processing-time assignment, the
-pipeline of `mps cusk` per block: correlation build -> stage one -> prune -> stage two -> reduction; .bed staged in
-HBM once per GPU), no collective in the data path.  Files: by default every rank writes the files of its own blocks
-(--writer local: what the reference's one-process-per-block runs do; only a barrier ends the pass); --writer rank0
-gathers the per-block results to rank 0 (ONE exchange over RCCL), which writes every file.  One step = one pass of the job over the whole chromosome.
+product's block driver (ci-gwas_amd/run_blocks.py: `cusk_blockset_*`, longest-processing-time assignment; the blocks of
+a rank run in batches -- `cusk_blockset_run_batch`: correlation build, stage one, prune, stage two and reduction of all
+blocks of a batch in one set of device runs; .bed staged in HBM once per GPU), no collective in the data path.  Files: by
+default the per-block results are gathered to rank 0 over RCCL -- the one exchange north_star names -- which writes every
+file (--writer rank0; the gather and the writing are timed separately); --writer local lets every rank write the files
+of its own blocks (what the reference's one-process-per-block runs do; only a barrier ends the pass); the line reports
+both.  One step = one pass of the job over the whole chromosome.
+
+EVERY line (N = 1 included) carries the same `scale` object -- the whole-chromosome job on this many GPUs, 25 blocks per
+GPU -- and `scale.blocks_per_sec` is the key a scaling curve is to be built from (at N = 1 `value` is the headline block,
+at N > 1 the chromosome job: not comparable with each other).
 
 Prints ONE JSON line on rank 0.
 """
@@ -162,7 +168,8 @@ def write_chromosome(workdir, rank, world, blocks_per_gpu, N, p, dist=None):
 
 
 def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
-    """K passes of the job over the synthetic chromosome.  Returns (dict for rank 0, stats of the last pass)."""
+    """K passes of the job over the synthetic chromosome, for the default writer and for the other one.  Returns
+    (scale object for rank 0, per-level detail of this rank's batches, seconds of the timed passes, canonical tests)."""
     import torch
 
     from cigwas_amd import run_blocks as rb
@@ -180,75 +187,162 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     phen, stem, blocks, sizes = write_chromosome(workdir, rank, world, args.blocks_per_gpu, N, p, dist)
     t_gen = time.time() - t0
     bs = rb.BlockSet(phen, stem, blocks, args.alpha, args.max_level, args.max_level_two, 1)
-    outdirs = []
+    bv = max(0, args.batch_vars)
+    counter = [0]
 
-    def one_pass(k, timing=0):
+    def one_pass(writer, timing=0, tm=None):
         out = None
-        if rank == 0 or args.writer == "local":
-            out = os.path.join(workdir, f"out{k}")
+        if rank == 0 or writer == "local":
+            counter[0] += 1
+            out = os.path.join(workdir, f"out{counter[0]}")
             os.makedirs(out, exist_ok=True)
-            outdirs.append(out)
-        # timed passes run without per-level HIP events (a dozen per engine run, a few microseconds of device time each:
-        # ~6 % of these launch-bound blocks); the per-level kernel times of the roofline come from one untimed detail pass
+        # timed passes run without per-level HIP events (a few microseconds of device time each); the per-level kernel
+        # times of the roofline come from one untimed detail pass
         return rb.run_job(bs, out, device, inflight=args.inflight, schedule=args.schedule, collective_device=cdev,
-                          options={"timing": timing}, writer=args.writer)
+                          options={"timing": timing}, writer=writer, batch_vars=bv, timings=tm)
 
-    for k in range(warmup):
-        one_pass(-1 - k)
-    _, detail_stats, _ = one_pass(-100, timing=1)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    tests = 0
-    canon = 0
-    agg = {}
-    for k in range(steps):
-        allr, stats, owned = one_pass(k)
-        for s in stats.values():
-            tests += int(s.tests[0]) + int(s.tests[1])
-            canon += int(sum(s.stage[0].canonical_tests)) + int(sum(s.stage[1].canonical_tests))
-            for key in ("ms_inputs", "ms_corr", "ms_stage1", "ms_prune", "ms_stage2", "ms_reduce"):
-                agg[key] = agg.get(key, 0.0) + float(getattr(s, key))
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt, float(tests), float(canon)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
-        tmax = t.clone()
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        dt, tests, canon = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
-    # per-level totals over this rank's blocks (last pass): which kernel dominates the device time
+    def totals(stats):
+        """(executed tests, canonical tests, phase sums) of one pass's stats (batched: list of batch stats; else per block)"""
+        ex = ca = 0
+        ph = {}
+        it = stats if bv > 0 else stats.values()
+        for s_ in it:
+            ex += int(s_.tests[0]) + int(s_.tests[1])
+            if bv > 0:
+                ca += int(s_.canonical[0]) + int(s_.canonical[1])
+            else:
+                ca += int(sum(s_.stage[0].canonical_tests)) + int(sum(s_.stage[1].canonical_tests))
+            for key in ("ms_corr", "ms_stage1", "ms_prune", "ms_stage2", "ms_reduce"):
+                ph[key[3:]] = ph.get(key[3:], 0.0) + float(getattr(s_, key))
+        return ex, ca, ph
+
+    def timed(writer, K, W):
+        for _ in range(W):
+            one_pass(writer)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ex = ca = 0
+        ph, tms = {}, {}
+        done = None
+        for _ in range(K):
+            tm = {}
+            done, stats, _owned = one_pass(writer, tm=tm)
+            e_, c_, p_ = totals(stats)
+            ex += e_
+            ca += c_
+            for k_, v_ in p_.items():
+                ph[k_] = ph.get(k_, 0.0) + v_
+            for k_, v_ in tm.items():
+                tms[k_] = tms.get(k_, 0.0) + v_
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt, float(ex), float(ca)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+            tmax = t.clone()
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            dt, ex, ca = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
+        nwritten = len(done) if done is not None else 0
+        if writer == "local" and dist is not None:
+            t = torch.tensor([float(nwritten)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            nwritten = int(t[0].item())
+        return dt, ex, ca, {k_: v_ / K for k_, v_ in ph.items()}, {k_: v_ / K * 1e3 for k_, v_ in tms.items()}, nwritten
+
+    one_pass(args.writer)  # first pass of the process: allocations, staging of the .bed
+    _, detail_stats, _ = one_pass("local", timing=1)
+    dt, ex, ca, ph, tms, nwritten = timed(args.writer, steps, warmup)
+    other = "local" if args.writer == "rank0" else "rank0"
+    dt2, _ex2, _ca2, _ph2, tms2, _nw2 = timed(other, steps, 1)
+    # per-level totals over this rank's blocks (detail pass): which kernel dominates the device time
     lv_ms, lv_tests, lv_sub, nvar = np.zeros(15), np.zeros(15), np.zeros(15), 0
-    for s in detail_stats.values():
-        for st in (s.stage[0], s.stage[1]):
+    for s_ in (detail_stats if bv > 0 else detail_stats.values()):
+        for st in (s_.stage[0], s_.stage[1]):
             for l in range(st.levels_run):
                 lv_ms[l] += st.main_kernel_ms[l]
                 lv_tests[l] += st.tests[l]
                 lv_sub[l] += st.subsets[l]
-        nvar = max(nvar, int(s.markers) + p)
-    nwritten = len(allr) if allr is not None else 0
-    if args.writer == "local" and dist is not None:
-        t = torch.tensor([float(nwritten)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        nwritten = int(t[0].item())
-    res = {
-        "blocks": len(sizes), "markers": int(sum(sizes)), "block_markers_min_mean_max": [int(min(sizes)), float(np.mean(sizes)), int(max(sizes))],
-        "blocks_written": nwritten, "passes": steps, "ms_per_pass": dt / steps * 1e3, "blocks_per_sec": len(sizes) * steps / dt,
-        "ci_tests_per_sec": canon / dt, "ci_tests_per_pass": canon / steps,
-        "executed_ci_tests_per_sec": tests / dt,
-        "rank0_phase_ms_per_pass": {k[3:]: v / steps for k, v in agg.items()},
-        "schedule": args.schedule, "inflight": args.inflight, "max_level": args.max_level, "max_level_two": args.max_level_two,
-        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); per-block files written inside the timed region",
+        nvar = max(nvar, int(s_.vars_stage1) if bv > 0 else int(s_.markers) + p)
+    nb = len(sizes)
+    scale = {
+        "workload": f"cusk whole-chromosome job through the block driver (BASELINE config 4's per-GPU share x {world}): {nb} unequal LD "
+                    f"blocks ({args.blocks_per_gpu} per GPU, {int(sum(sizes))} SNPs, sizes min/mean/max "
+                    f"{[int(min(sizes)), float(np.mean(sizes)), int(max(sizes))]}) x {p} traits, N={N}, alpha={args.alpha:g}, max level "
+                    f"{args.max_level}, max level two {args.max_level_two}, depth 1; one pass = .bed (in HBM) -> correlations -> stage one "
+                    f"-> prune -> stage two -> reduction -> result files",
+        "n_gpus": world, "blocks": nb, "blocks_per_gpu": args.blocks_per_gpu, "passes": steps,
         "writer": args.writer,
+        "blocks_per_sec": nb * steps / dt, "ms_per_pass": dt / steps * 1e3, "blocks_written_per_pass": nwritten,
+        "gather_ms": tms.get("gather_s", 0.0) if args.writer == "rank0" else 0.0,
+        "write_ms": tms.get("write_s"), "compute_ms": tms.get("compute_s"),
+        "rank0_phase_ms_per_pass": ph,
+        "ci_tests_per_sec": ca / dt, "ci_tests_per_pass": ca / steps, "executed_ci_tests_per_sec": ex / dt,
+        "other_writer": {"writer": other, "blocks_per_sec": nb * steps / dt2, "ms_per_pass": dt2 / steps * 1e3,
+                         "gather_ms": tms2.get("gather_s", 0.0) if other == "rank0" else 0.0},
+        "execution": (f"batched: blocks of a rank in batches of <= {bv} padded variables, one correlation build / level loop per stage / read-out "
+                      f"per batch (cusk_blockset_run_batch)") if bv > 0 else "one block per engine run (cusk_blockset_run_block)",
+        "batch_vars": bv, "schedule": args.schedule,
+        "gather": ("per-block reduced results of every rank -> rank 0: size all_gather + one padded all_gather over "
+                   + ("RCCL (backend nccl)" if cdev is not None else ("gloo" if dist is not None else "nothing (one rank)"))
+                   + "; rank 0 writes every file (gather_ms, write_ms: rank 0's wall clock per pass)"),
+        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); result files written inside the timed region",
+        "curve_key": "scale.blocks_per_sec (same workload definition at every N: 25 blocks per GPU, weak scaling)",
         "generate_s": t_gen,
     }
     bs.close()
     if rank == 0:
         shutil.rmtree(workdir, ignore_errors=True)
-    return res, (lv_ms, lv_tests, lv_sub, nvar), dt, canon
+    return scale, (lv_ms, lv_tests, lv_sub, nvar), dt, ca
+
+
+def e2e_block(args, bed, phen, means, stds, device):
+    """BASELINE metric "wall-clock per 10k-SNP block at l <= 5": the headline block as a PLINK file set through
+    cusk_blockset_run_block -- the code `mps cusk` runs (cli.cpp:521-677): correlation build from the packed genotypes (staged
+    in HBM), stage one, prune, stage two (both at max level l), reduction -- plus writing the five result files."""
+    from cigwas_amd import run_blocks as rb
+    from cigwas_amd import synth
+    from cigwas_amd.skeleton import Engine
+
+    m, p, N = args.markers, args.traits, args.individuals
+    d = tempfile.mkdtemp(prefix="cusk_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    try:
+        stem = os.path.join(d, "blk")
+        synth.write_bfiles(stem, bed, N, means, stds)
+        synth.write_phen_fast(os.path.join(d, "y.phen"), np.asarray(phen, np.float32).reshape(p, N))
+        synth.write_blocks_file(os.path.join(d, "b.blocks"), [m])
+        bs = rb.BlockSet(os.path.join(d, "y.phen"), stem, os.path.join(d, "b.blocks"), args.alpha, args.max_level, args.max_level, 1)
+        eng = Engine(device)
+        eng.set_option("timing", 0)
+        bs.stage(eng)
+        out = os.path.join(d, "out")
+        os.makedirs(out)
+        walls, phases = [], {}
+        for k in range(4):
+            t0 = time.perf_counter()
+            br, st = bs.run_block(eng, 0)
+            t1 = time.perf_counter()
+            br.write(out)
+            t2 = time.perf_counter()
+            if k:  # the first call allocates
+                walls.append((t2 - t0) * 1e3)
+                for key in ("ms_inputs", "ms_corr", "ms_stage1", "ms_prune", "ms_stage2", "ms_reduce"):
+                    phases[key[3:]] = phases.get(key[3:], 0.0) + float(getattr(st, key)) / 3
+                phases["write"] = phases.get("write", 0.0) + (t2 - t1) * 1e3 / 3
+        res = {"e2e_block_ms": float(np.median(walls)), "phases_ms": phases, "retained_markers": int(st.retained),
+               "ci_tests": [int(st.tests[0]), int(st.tests[1])], "max_level": args.max_level, "max_level_two": args.max_level,
+               "path": "cusk_blockset_run_block (csrc/host/block_pipeline.h = `mps cusk`'s pipeline) + the five result files; .bed staged in HBM, "
+                       "matrix never leaves the device between build and sweeps"}
+        lib_release = rb.lib().cusk_blockset_release_engine
+        lib_release(bs.h, eng.h)
+        eng.close()
+        bs.close()
+        return res
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def main():
@@ -266,15 +360,20 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=25, help="chromosome workload: LD blocks per GPU (config C4: 200 on 8 GPUs)")
     ap.add_argument("--inflight", type=int, default=1, help="chromosome workload: blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
-    ap.add_argument("--writer", choices=["local", "rank0"], default="local",
-                    help="chromosome workload: local = every rank writes the files of its own blocks (no exchange, as the "
-                         "reference's one process per block); rank0 = one gather of all results, rank 0 writes every file")
+    ap.add_argument("--writer", choices=["local", "rank0"], default="rank0",
+                    help="chromosome workload: rank0 = one gather of all results (RCCL), rank 0 writes every file; local = every rank "
+                         "writes the files of its own blocks (no exchange, as the reference's one process per block).  Both are measured, "
+                         "this one is the line's blocks_per_sec")
+    ap.add_argument("--batch-vars", type=int, default=16384,
+                    help="chromosome workload: blocks run in batches of at most this many padded variables (0: one block per engine run)")
+    ap.add_argument("--scale-steps", type=int, default=5, help="N = 1: timed passes of the whole-chromosome leg (the `scale` object)")
     ap.add_argument("--alpha", type=float, default=1e-4)
     ap.add_argument("--engine", choices=["cusk", "cuskss"], default="cusk",
                     help="block workload: cusk = Skeleton engine (sepsets + pMax); cuskss = hetcor engine with uniform ESS")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo to rehearse on one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-chromosome", action="store_true", help="N = 1: skip the bounded whole-chromosome pass")
+    ap.add_argument("--no-chromosome", action="store_true", help="N = 1: skip the bounded whole-chromosome pass (the `scale` object)")
+    ap.add_argument("--e2e", action="store_true", help="N = 1: the end-to-end block figure also for a non-headline configuration")
     ap.add_argument("--option", action="append", default=[], metavar="KEY=VALUE",
                     help="engine option for kernel experiments (cusk_set_option); the default run sets none")
     ap.add_argument("--cpu-sample-markers", type=int, default=10000)
@@ -304,8 +403,8 @@ def main():
     workload = args.workload if args.workload != "auto" else ("block" if world == 1 else "chromosome")
 
     if workload == "chromosome":
-        res, (lv_ms, lv_tests, lv_sub, nvar), dt, tests = chromosome_run(args, rank, world, local_rank, cdev,
-                                                                         dist if world > 1 else None, args.steps, args.warmup)
+        scale, (lv_ms, lv_tests, lv_sub, nvar), dt, tests = chromosome_run(args, rank, world, local_rank, cdev,
+                                                                           dist if world > 1 else None, args.steps, args.warmup)
         if rank == 0:
             K = args.steps
             lv = int(np.argmax(lv_ms[1:]) + 1) if lv_ms[1:].sum() > 0 else 0
@@ -314,21 +413,17 @@ def main():
                 "warmup": args.warmup, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {
-                    "workload": f"cusk whole-chromosome job through the block driver (BASELINE config 4): {res['blocks']} unequal LD blocks "
-                                f"({args.blocks_per_gpu} per GPU, {res['markers']} SNPs, sizes {res['block_markers_min_mean_max']}) x "
-                                f"{args.traits} traits, N={args.individuals}, alpha={args.alpha:g}, max level {args.max_level}, "
-                                f"max level two {args.max_level_two}, depth 1; one step = one pass over the chromosome "
-                                f"(.bed -> correlations -> stage one -> prune -> stage two -> reduction -> "
-                                f"{'files written by the owning rank' if args.writer == 'local' else 'gather -> files written by rank 0'})",
-                    "blocks_per_step": res["blocks"], "engine": "cusk", "parallelism": f"block-sharded x{world}, {args.schedule}",
+                    "workload": scale["workload"],
+                    "blocks_per_step": scale["blocks"], "engine": "cusk", "parallelism": f"block-sharded x{world}, {args.schedule}",
                 },
                 "value_counts": "canonical CI tests of both stages (cusk_stats.canonical_tests: the sequential schedule, device counter); "
-                                "chromosome.executed_ci_tests_per_sec = what the parallel sweeps executed",
-                "blocks_per_sec": res["blocks_per_sec"],
+                                "scale.executed_ci_tests_per_sec = what the parallel sweeps executed",
+                "blocks_per_sec": scale["blocks_per_sec"],
+                "scaling_curve_key": scale["curve_key"],
                 "roofline": roofline_of(lv, lv_tests[lv], lv_sub[lv], nvar, lv_ms[lv], "cusk"),
-                "chromosome": res,
+                "scale": scale,
             }
-            out["roofline"]["note"] = ("rank 0's blocks of an untimed detail pass (per-level HIP events on), summed over blocks and both stages: the level whose dominant kernel "
+            out["roofline"]["note"] = ("rank 0's batches of an untimed detail pass (per-level HIP events on), summed over batches and both stages: the level whose dominant kernel "
                                        "takes the most device time; " + out["roofline"]["note"])
             print(json.dumps(out))
         if world > 1:
@@ -469,7 +564,7 @@ def main():
         },
         "levels_note": f"sweep_ms / level_ms and the durations of level_rooflines other than level {lv}: detail pass of {D} untimed steps "
                        "with per-level HIP events (timing = 1); the timed steps record only the pair around the dominant kernel",
-        "blocks_per_sec": K / dt,
+        "headline_block_sweeps_per_sec": K / dt,
         "filter_violations": int(st.violations), "exact_fallbacks": int(st.exact_fallbacks),
         "corr_build_ms": {"decode": corr_ms[0], "snp_x_snp": corr_ms[1], "snp_trait_and_trait_trait": corr_ms[2],
                           "total_incl_h2d": corr_ms[3]},
@@ -485,10 +580,15 @@ def main():
         # the dominant kernel's roofline on the CANONICAL tests of its level: the engine executes more tests than that
         # (lanes cannot see each other's fresh verdicts; level 1 evaluates every pair), so this is the figure that cannot be
         # inflated by doing needless work; roofline_executed = the same with the launch's own test counter
-        out["roofline_executed"] = out["roofline"]
+        ex_r = out["roofline"]
         out["roofline"] = roofline_of(lv, int(st.canonical_tests[lv]), int(st.subsets[lv]), n, main_ms[lv], args.engine, traffic)
         out["roofline_counts"] = ("tests of the dominant kernel's level in the CANONICAL (sequential) schedule (device counter, equal to "
-                                  "the oracle's count: parity.canonical_count_equal); roofline_executed: the launch's own test counter")
+                                  "the oracle's count: parity.canonical_count_equal)")
+        # NOT a roofline (the operands of the extra tests come from LDS, not HBM): how many tests the launch executed per second
+        out["dominant_kernel_executed_tests"] = {"tests_per_launch": int(st.tests[lv]), "tests_per_sec": float(st.tests[lv]) / (main_ms[lv] * 1e-3) if main_ms[lv] > 0 else 0.0,
+                                                 "bytes_equivalent_per_sec": ex_r["achieved"] * 1e9,
+                                                 "note": "the launch evaluates every pair of a row (lanes cannot see each other's fresh verdicts); the byte figure prices those tests "
+                                                         "with SURVEY 8(d)'s 12 B as if their operands came from HBM -- they come from LDS, so this is a rate, not a roofline fraction"}
     if not args.no_cpu_baseline:
         nall = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         from oracle import oracle as O
@@ -580,10 +680,14 @@ def main():
         del Ch, sub, sub1, ref, r64
     Cd.free()
     eng.close()
+    if headline or args.e2e:
+        out["e2e_block"] = e2e_block(args, bed, phen, means, stds, local_rank)
+        out["e2e_block_ms"] = out["e2e_block"]["e2e_block_ms"]
     if not args.no_chromosome:
         a2 = argparse.Namespace(**vars(args))
-        res, _lvs, _dt, _tests = chromosome_run(a2, 0, 1, local_rank, None, None, 3, 1)
-        out["chromosome"] = res
+        scale, _lvs, _dt, _tests = chromosome_run(a2, 0, 1, local_rank, None, None, args.scale_steps, 1)
+        out["scale"] = scale
+        out["scaling_curve_key"] = scale["curve_key"]
     print(json.dumps(out))
 
 

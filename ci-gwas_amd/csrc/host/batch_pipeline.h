@@ -10,6 +10,9 @@
 // run_cusk_block (block_pipeline.h) -- the files are byte-identical (tests/test_gpu_batch.py) -- because the blocks never
 // interact: a row only meets columns of its own block.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
+
 #include "block_pipeline.h"
 
 namespace host {
@@ -63,6 +66,16 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
         return v;
     };
     bs = BatchStats();
+    // CUSK_BATCH_PROF=1: wall-clock marks of this function on stderr (microseconds since entry)
+    static const bool prof = std::getenv("CUSK_BATCH_PROF") != nullptr;
+    const auto p0 = clk::now();
+    std::string plog;
+    auto mark = [&](const char *what) {
+        if (!prof) return;
+        char buf[64];
+        std::snprintf(buf, sizeof(buf), " %s=%.0f", what, std::chrono::duration<double, std::micro>(clk::now() - p0).count());
+        plog += buf;
+    };
     const int B = (int)blocks.size();
     outs.assign((size_t)B, BatchBlockOut());
     if (B == 0) return;
@@ -100,9 +113,11 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     if (cusk_corr_build_batch_mxp(e, staged.bed, staged.phen, staged.means, staged.stds, N, p, B, first.data(), m.data(), base.data(),
                                   (int)n1, scr.C.p, mxp.data()) != CUSK_OK)
         engine_die("correlation build (marker x trait)", e);
+    mark("mxp");
     std::vector<unsigned char> keep((size_t)B, 0);
     std::vector<int> kept;
     {
+        const double c_lo = std::tanh((double)in.Th[0]) * (1.0 - 1e-6), c_hi = std::tanh((double)in.Th[0]) * (1.0 + 1e-6);
         size_t o = 0;
         for (int b = 0; b < B; b++)
         {
@@ -110,7 +125,17 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
             const size_t cnt = (size_t)m[(size_t)b] * p;
             for (size_t i = 0; i < cnt; i++)
             {
+                // |atanh c| >= Th[0] is a comparison of |c| with tanh(Th[0]): only the elements within 1e-6 (relative) of
+                // that value, NaN and |c| >= 1 go through the reference's expression (cli.cpp:561-565) -- the two logs cost
+                // 1 ms per 14,000 markers x 20 traits otherwise
                 const float c = mxp[o + i];
+                const double ac = std::fabs((double)c);
+                if (ac < c_lo) continue;
+                if (ac > c_hi && ac < 1.0)
+                {
+                    num_sig++;
+                    continue;
+                }
                 num_sig += (std::fabs(0.5 * (std::log(std::fabs((1 + c))) - std::log(std::fabs(1 - c)))) >= in.Th[0]);
             }
             o += cnt;
@@ -123,6 +148,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
                 bs.skipped++;
         }
     }
+    mark("prefilter");
     if (kept.empty())
     {
         bs.ms_corr = ms_since(t);
@@ -131,6 +157,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     if (cusk_corr_build_batch_mxm(e, staged.bed, staged.phen, staged.means, staged.stds, N, p, B, first.data(), m.data(), base.data(),
                                   keep.data(), (int)n1, scr.C.p) != CUSK_OK)
         engine_die("correlation build (marker x marker)", e);
+    mark("mxm_enq");
     bs.ms_corr = ms_since(t);
 
     // ---- stage one: one level loop for every kept block ----
@@ -143,6 +170,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     }
     if (cusk_run_skeleton_batch(e, scr.C.p, (int)n1, K, lo1.data(), hi1.data(), in.Th, in.max_level, &bs.stage[0]) != CUSK_OK)
         engine_die("Skeleton (batch)", e);
+    mark("stage1");
     for (int l = 0; l < bs.stage[0].levels_run; l++)
     {
         bs.tests[0] += bs.stage[0].tests[l];
@@ -158,6 +186,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
         packed.resize(words);
         if (cusk_result_adj_bits_blocks(e, packed.data()) != CUSK_OK) engine_die("adjacency (batch)", e);
     }
+    mark("bits1");
     std::vector<std::vector<int>> P1((size_t)K);
     std::vector<int> lo2((size_t)K), hi2((size_t)K);
     size_t n2 = 0, rows2 = 0;
@@ -174,6 +203,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
             rows2 += P1[(size_t)k].size();
         }
     }
+    mark("bfs1");
     bs.vars_stage2 = (long long)n2;
     scr.C2.reserve(n2 * n2);
     {
@@ -197,11 +227,13 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
                              row_out.data(), (long long)rows2, scr.C2.p, 0, 1) != CUSK_OK)
             engine_die("gather (batch)", e);
     }
+    mark("gather2");
     bs.ms_prune = ms_since(t);
 
     // ---- stage two: Skeleton again on every reduced set, each from its complete graph ----
     if (cusk_run_skeleton_batch(e, scr.C2.p, (int)n2, K, lo2.data(), hi2.data(), in.Th, in.max_level_two, &bs.stage[1]) != CUSK_OK)
         engine_die("Skeleton (stage two, batch)", e);
+    mark("stage2");
     for (int l = 0; l < bs.stage[1].levels_run; l++)
     {
         bs.tests[1] += bs.stage[1].tests[l];
@@ -216,6 +248,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
         packed.resize(words);
         if (cusk_result_adj_bits_blocks(e, packed.data()) != CUSK_OK) engine_die("adjacency (stage two, batch)", e);
     }
+    mark("bits2");
     std::vector<std::vector<int>> P2((size_t)K);
     size_t rows3 = 0, cells3 = 0;
     {
@@ -266,6 +299,7 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
             cell += kk * kk;
         }
     }
+    mark("adj_corr");
     // separating sets: the sparse records of the stage-two run (ordered by (x, y), i.e. block after block), reduced as
     // reduce_sepsets does, including the stage-two remap quirk: a member s (an index of the stage-two
     // space) is looked up in a map keyed by the STAGE-ONE index of the retained variables
@@ -318,7 +352,9 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
             }
         }
     }
+    mark("sepsets");
     bs.ms_reduce = ms_since(t);
+    if (prof) std::fprintf(stderr, "[batchprof]%s\n", plog.c_str());
 }
 
 }  // namespace host
