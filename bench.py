@@ -186,6 +186,12 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     t0 = time.time()
     phen, stem, blocks, sizes = write_chromosome(workdir, rank, world, args.blocks_per_gpu, N, p, dist)
     t_gen = time.time() - t0
+    # the synthetic inputs were written a moment ago (hundreds of MB of dirty pages): without this the kernel's write-back
+    # throttling lands on the result files of the timed passes (measured: 15-20 ms instead of 2 ms per 25 blocks)
+    if rank == 0:
+        os.sync()
+    if dist is not None:
+        dist.barrier()
     bs = rb.BlockSet(phen, stem, blocks, args.alpha, args.max_level, args.max_level_two, 1)
     bv = max(0, args.batch_vars)
     counter = [0]

@@ -379,6 +379,7 @@ extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const ch
     try
     {
         check_path(outdir);
+        const auto t0 = std::chrono::steady_clock::now();
         const char *p = static_cast<const char *>(buf), *end = p + bytes;
         std::vector<std::unique_ptr<cusk_block_result>> parsed;
         bool all_sep = true;
@@ -413,10 +414,15 @@ extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const ch
         }
         std::vector<const cusk_block_result *> items;
         for (auto &b : parsed) items.push_back(b.get());
+        const auto t1 = std::chrono::steady_clock::now();
         if (all_sep)
             write_many(items, outdir, true);
         else
             for (const cusk_block_result *b : items) write_reduced(b->r, make_path(outdir, b->stem, ""), !b->r.S.empty());
+        if (std::getenv("CUSK_BATCH_PROF"))
+            std::fprintf(stderr, "[writeprof] %zu blocks, %zu bytes: parse %.0f us, write %.0f us\n", items.size(), bytes,
+                         std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count());
     }
     catch (const std::exception &ex)
     {
