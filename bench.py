@@ -545,6 +545,7 @@ def main():
         "value_counts": "executed CI tests (device counters)",
         "executed_tests_per_step": tests_total / K,
         "canonical_tests_per_step_device": int(sum(st.canonical_tests)) if args.engine == "cusk" else None,
+        "canonical_tests_by_level_device": [int(v) for v in st.canonical_tests[: st.levels_run]],
         "roofline": roofline_of(lv, st.tests[lv], st.subsets[lv], n, main_ms[lv], args.engine, traffic),
         "roofline_counts": "tests and conditioning sets the dominant kernel EXECUTED in one launch (device counters)",
         "level_rooflines": {str(l): {k: v for k, v in roofline_of(l, st.tests[l], st.subsets[l], n, main_ms[l], args.engine).items()
@@ -595,6 +596,14 @@ def main():
                                                  "bytes_equivalent_per_sec": ex_r["achieved"] * 1e9,
                                                  "note": "the launch evaluates every pair of a row (lanes cannot see each other's fresh verdicts); the byte figure prices those tests "
                                                          "with SURVEY 8(d)'s 12 B as if their operands came from HBM -- they come from LDS, so this is a rate, not a roofline fraction"}
+    elif args.engine == "cuskss" and st.canonical_tests[lv] > 0:
+        # hetcor engine: the finaliser of level 1 counts the canonical tests on the device (cusk_stats.canonical_tests[1]; the
+        # deeper levels are not counted there): the dominant kernel's roofline is on canonical tests, as the cusk line's
+        ex_r = out["roofline"]
+        out["roofline"] = roofline_of(lv, int(st.canonical_tests[lv]), int(st.subsets[lv]), n, main_ms[lv], args.engine, traffic)
+        out["roofline_counts"] = "tests of the dominant kernel's level in the CANONICAL (sequential) schedule (device counter of level1_apply_kernel)"
+        out["dominant_kernel_executed_tests"] = {"tests_per_launch": int(st.tests[lv]), "tests_per_sec": float(st.tests[lv]) / (main_ms[lv] * 1e-3) if main_ms[lv] > 0 else 0.0,
+                                                 "bytes_equivalent_per_sec": ex_r["achieved"] * 1e9, "note": "a rate, not a roofline fraction (see the cusk line)"}
     if not args.no_cpu_baseline:
         nall = args.cpu_threads or min(16, len(os.sched_getaffinity(0)))
         from oracle import oracle as O
@@ -651,6 +660,9 @@ def main():
                 par["canonical_count_equal"] = bool(int(sum(st.canonical_tests)) == int(ref.tests.sum()))
                 out["parity_ok"] = bool(out["parity_ok"] and par["canonical_count_equal"])
             else:
+                if st.canonical_tests[1] > 0:
+                    par["canonical_count_level1_equal"] = bool(int(st.canonical_tests[1]) == int(ref.tests[1]))
+                    out["parity_ok"] = bool(out["parity_ok"] and par["canonical_count_level1_equal"])
                 out["value_executed"] = out["value"]
                 out["value"] = float(ref.tests.sum()) / (dt / K)
                 out["value_counts"] = ("canonical CI tests (counted by the oracle on this very matrix) / measured time; "

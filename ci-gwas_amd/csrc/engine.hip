@@ -197,7 +197,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
     local.max_degree[0] = n - 1;
     local.edges[0] = (long long)n * (n - 1);
     local.tests[0] = a.row_range ? a.level0_pairs : (long long)n * (n - 1) / 2;
-    local.canonical_tests[0] = a.mode == 0 ? local.tests[0] : 0;
+    local.canonical_tests[0] = local.tests[0];
     local.levels_run = 1;
 
     LevelPlan plan[kLevels];
@@ -225,7 +225,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             CUSK_HIP(e, launch_level1_rows(a.mode, e->opt_validate != 0, pl.filter_ok && e->opt_fast != 0, sp, e->rv.as<float>(),
                                            e->rpos.p, e->sel.as<unsigned>(), e->wpre.as<int>(), e->opt_timing ? e->ev_main[0] : nullptr,
                                            e->opt_timing ? e->ev_main[1] : nullptr, e->shard_rank, e->shard_world, e->opt_l1_exp, sharded,
-                                           a.time_index != nullptr, s));
+                                           a.time_index != nullptr, (a.mode == 1) ? dcanon + (size_t)l * kCounterSlots : nullptr, s));
             rows_timed = true;
             return CUSK_OK;
         }
@@ -729,7 +729,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             local.subsets[l] += (long long)sl[1];
             local.removed[l] += (long long)sl[2];
             local.violations += (long long)sl[3];
-            if (a.mode == 0) local.canonical_tests[l] += (long long)e->hcanon[(size_t)l * kCounterSlots + k];
+            // (hetcor: counted at level 1 by level1_apply_kernel when no time index is given; 0 elsewhere)
+            if (a.mode == 0 || l == 1) local.canonical_tests[l] += (long long)e->hcanon[(size_t)l * kCounterSlots + k];
         }
         local.rechecks[l] = (long long)e->hcnt[l].qcount;
         if (!timed)

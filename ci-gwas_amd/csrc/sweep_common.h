@@ -304,7 +304,7 @@ hipError_t launch_expand_records(const int *rec_s, const int *rec_l, long long r
                                  hipStream_t st);
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, int exp, bool defer_apply, bool has_ti, hipStream_t st);
+                              int shard_world, int exp, bool defer_apply, bool has_ti, unsigned long long *canon, hipStream_t st);
 // hetcor mode, row-sharded runs: adjacency bitmap -> per-slot marks (0 gone / all ones alive), and back after the join
 hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStream_t st);
 hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, const void *meta, bool count_removed, hipStream_t st);

@@ -1605,12 +1605,13 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
             }
             else
             {
-                // hetcor: the edge goes in both directions; both directed slots are marked with plain stores (racing
-                // writers store the same 0), bitmap and degrees are updated once afterwards (level1_apply_kernel)
-                // (only the slot of the ordered pair that was tested; level1_apply_kernel removes the edge in both directions)
-                if (passB0) rp.sel[cur.ib] = 0u;
-                if (passB1) rp.sel[cur.ib + 1] = 0u;
-                if (headA) rp.sel[cur.ia] = 0u;
+                // hetcor: the edge goes in both directions; only the slot of the ordered pair that was tested is marked
+                // (level1_apply_kernel removes the edge when either direction is marked, updates bitmap and degrees once).
+                // The mark is the lowest passing position, as in Skeleton mode: anything but kNone32 means "gone", and the
+                // position lets level1_apply_kernel count the tests of the canonical schedule (round 2 stored plain zeros)
+                if (passB0) (void)__hip_atomic_fetch_min(&rp.sel[cur.ib], (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (passB1) (void)__hip_atomic_fetch_min(&rp.sel[cur.ib + 1], (unsigned)a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (headA) (void)__hip_atomic_fetch_min(&rp.sel[cur.ia], (unsigned)bsel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
         // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
@@ -1668,13 +1669,15 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
 __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict__ off, const int *__restrict__ nbr,
                                                            const unsigned *__restrict__ sel, unsigned long long *adj, int *deg,
                                                            int n, int words, unsigned long long *slots, const LevelCounters *cnt,
-                                                           const int4 *__restrict__ meta)
+                                                           const int4 *__restrict__ meta, unsigned long long *canon)
 {
     __shared__ int s_sum[4];
+    __shared__ unsigned long long s_can[4];
     if (!cnt->active) return;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     int removed = 0;
+    unsigned long long ctests = 0;
     if (row < n)
     {
         const int o0 = off[row], d = off[row + 1] - o0;
@@ -1683,11 +1686,16 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
             const int k = k0 + lane;
             const bool valid = k < d;
             const int Y = valid ? nbr[o0 + k] : 0;
-            bool gone = valid && (sel[o0 + k] == 0u);
+            const unsigned mark = valid ? sel[o0 + k] : kNone32;
+            bool gone = valid && (mark != kNone32);
+            // canonical (sequential) schedule of this ordered pair at level 1: the neighbour at position k is tested with the
+            // positions 0, 1, ... (without k itself) up to its lowest passing one, or with all d - 1 of them
+            if (canon != nullptr && valid)
+                ctests += gone ? (unsigned long long)(mark + 1u - (mark > (unsigned)k ? 1u : 0u)) : (unsigned long long)(d - 1);
             if (valid && !gone && meta != nullptr)
             {
                 const int4 m = meta[o0 + k];
-                gone = (sel[m.z + m.y] == 0u);
+                gone = (sel[m.z + m.y] != kNone32);
             }
             const int w = valid ? (Y >> 6) : -1 - lane;
             unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
@@ -1704,13 +1712,21 @@ __global__ void __launch_bounds__(256) level1_apply_kernel(const int *__restrict
         }
         if (lane == 0 && removed) deg[row] = d - removed;
     }
-    if (lane == 0) s_sum[threadIdx.x >> 6] = removed;
+    if (canon != nullptr)
+        for (int o = 32; o > 0; o >>= 1) ctests += __shfl_xor(ctests, o);
+    if (lane == 0)
+    {
+        s_sum[threadIdx.x >> 6] = removed;
+        s_can[threadIdx.x >> 6] = ctests;
+    }
     __syncthreads();
     if (threadIdx.x == 0)
     {
         const int t = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
         // cusk_stats.removed: ordered pairs, as in Skeleton mode (both directions of an edge go)
         if (t && slots) atomicAdd(&slots[(size_t)(blockIdx.x & (kCounterSlots - 1)) * 4 + 2], (unsigned long long)t);
+        const unsigned long long c = s_can[0] + s_can[1] + s_can[2] + s_can[3];
+        if (c && canon) atomicAdd(&canon[blockIdx.x & (kCounterSlots - 1)], c);
     }
 }
 
@@ -1743,13 +1759,13 @@ hipError_t launch_marks_from_bitmap(const SweepParams &p, unsigned *sel, hipStre
 hipError_t launch_level1_apply(const SweepParams &p, const unsigned *sel, const void *meta, bool count_removed, hipStream_t st)
 {
     hipLaunchKernelGGL(level1_apply_kernel, dim3((p.n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, p.n, p.words,
-                       count_removed ? p.slots : nullptr, p.cnt, static_cast<const int4 *>(meta));
+                       count_removed ? p.slots : nullptr, p.cnt, static_cast<const int4 *>(meta), (unsigned long long *)nullptr);
     return hipGetLastError();
 }
 
 hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const SweepParams &p, float *rv, void *meta,
                               unsigned *sel, const int *wpre, hipEvent_t ev_begin, hipEvent_t ev_end, int shard_rank,
-                              int shard_world, int exp, bool defer_apply, bool has_ti, hipStream_t st)
+                              int shard_world, int exp, bool defer_apply, bool has_ti, unsigned long long *canon, hipStream_t st)
 {
     const int n = p.n;
     hipLaunchKernelGGL(level1_prep_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.C, p.off, p.nbr, p.adj, wpre, p.words, rv,
@@ -1852,7 +1868,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (ev_end) (void)hipEventRecord(ev_end, st);
     if (mode != 0 && !defer_apply)
         hipLaunchKernelGGL(level1_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, p.off, p.nbr, sel, p.adj, p.deg, n,
-                           p.words, p.slots, p.cnt, static_cast<const int4 *>(meta));
+                           p.words, p.slots, p.cnt, static_cast<const int4 *>(meta), (two && !has_ti) ? canon : nullptr);
     return hipGetLastError();
 }
 

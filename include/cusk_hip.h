@@ -108,7 +108,9 @@ typedef struct cusk_stats {
                                          algorithm run sequentially per row: a neighbour is tested with every conditioning
                                          set up to its lowest passing one -- computed on the device from
                                          the selected ranks; `tests` counts what the parallel sweep executed (more: lanes
-                                         cannot see each other's fresh verdicts).  0 for cusk_run_hetcor. */
+                                         cannot see each other's fresh verdicts).  cusk_run_hetcor: level 0 and -- on a
+                                         symmetric matrix with one sample size and no time index (the row-streaming
+                                         kernel) -- level 1; 0 at the other levels. */
 } cusk_stats;
 
 /* device = HIP device ordinal; stream = a hipStream_t to run on, or NULL for a

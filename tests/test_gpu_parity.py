@@ -126,6 +126,12 @@ def test_hetcor_uniform_ess(cg, eng, oracle, synth, m, p, maxlevel):
     st = eng.run_hetcor(Cd.ptr, n, th, maxlevel, ess_uniform=4096.0, time_index=ti)
     assert st.level == ref.level
     assert np.array_equal(eng.adjacency(), ref.G)
+    assert st.canonical_tests[1] == 0  # with a time index the canonical schedule is not counted on the device
+    # without a time index the level-1 finaliser counts the tests of the canonical (sequential) schedule: the oracle's
+    ref0 = oracle.hetcor_skeleton(Cm, np.ones((n, n), np.int32), np.full((n, n), 4096, np.float32), th, maxlevel, np.zeros(n, np.int32))
+    st0 = eng.run_hetcor(Cd.ptr, n, th, maxlevel, ess_uniform=4096.0)
+    assert st0.level == ref0.level and np.array_equal(eng.adjacency(), ref0.G)
+    assert list(st0.canonical_tests[:2]) == [int(ref0.tests[0]), int(ref0.tests[1])] and st0.tests[1] >= ref0.tests[1]
     Cd.free()
 
 
