@@ -143,9 +143,10 @@ struct cusk_engine
     long long opt_chunk0_low = 256;  // ... at levels 2-4
     int opt_vec_threads = 64;     // workgroup size of sweep_vec_kernel for the first degree class (64 / 128 / 256)
     long long opt_item_cap = 1ll << 20;  // work items per degree class and level the buffers hold before they are grown
-    int opt_lookahead = 2;
+    int opt_lookahead = 2;               // levels the host may enqueue ahead of the counters it has seen
+    int opt_sync2 = 1;                   // the host reads level 2's gate record before it enqueues that level's sweeps (engine.hip)
     int opt_l1_exp = 0;                  // level-1 row kernel experiment bits (sweep_level.hip: RowsParams::exp)
-    int opt_timing = 1;                  // per-level HIP events for cusk_stats' kernel_ms / level_ms (0: total only)               // levels the host may enqueue ahead of the counters it has seen
+    int opt_timing = 1;                  // per-level HIP events for cusk_stats' kernel_ms / level_ms (0: total only)
     long long opt_sep_ws_budget = 4ll << 30;  // HBM work space of cusk_sepselect_greedy for candidate lists beyond LDS
 
     // row-sharded sweep of ONE block over several engines: this engine runs the tests of rows

@@ -189,7 +189,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         {
             CUSK_HIP(e, launch_level0(a.C, het ? a.Ness : nullptr, a.Ginit, e->adj.as<unsigned long long>(), n, words, th0,
                                       e->opt_assume_symmetric ? nullptr : dsym, s));
-            if (a.mode == 0) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
+            // (Skeleton mode keeps the bitmap of level 0: the degree pass below writes the copy; without a level 1 nobody reads it
+            // but the pMax read-out, which then needs the copy made here)
+            if (a.mode == 0 && last_level < 1) CUSK_HIP(e, hipMemcpyAsync(e->adj0.p, e->adj.p, bm, hipMemcpyDeviceToDevice, s));
         }
     }
     CUSK_HIP(e, hipEventRecord(e->ev_l1[0], s));
@@ -354,7 +356,9 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         return CUSK_OK;
     };
 
-    if (last_level >= 1 && !a.row_range) CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words, s));
+    if (last_level >= 1 && !a.row_range)
+        CUSK_HIP(e, launch_degree(e->adj.as<unsigned long long>(), e->deg.as<int>(), n, words,
+                                  a.mode == 0 ? e->adj0.as<unsigned long long>() : nullptr, s));
 
     // which classes can be staged in LDS in this mode
     int staged_classes = 0;
@@ -388,6 +392,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         return CUSK_OK;
     };
     int maxdeg1 = 0;
+    int maxdeg2 = -1;  // maximum degree at the start of level 2, once the host has seen it
     int start = 1;   // first level to enqueue in this pass
     int redo = 0;    // level whose recheck queue overflowed: its sweeps run again on the exact path before `start`
     bool first_pass = true;
@@ -407,6 +412,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
             redo = 0;
         }
         int enq_last = start - 1;
+        int planned_last = start - 1;  // last level whose plan kernel was enqueued (>= enq_last)
         for (int l = start; l <= last_level; l++)
         {
             const int cs = l & 1;
@@ -479,6 +485,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 pa.binom = e->binom.as<unsigned long long>();
             }
             CUSK_HIP(e, launch_plan(pa, s));
+            planned_last = l;
             if (first_build)
             {
                 // the run's one mandatory round trip: sizes of the CSR arrays and of the binomial table come from the
@@ -549,17 +556,31 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 for (int c = 0; c < kNumClasses; c++) pl.nitems[c] = e->hgate[l].class_items[c];
                 pl.known_items = true;
             }
-            {  // degrees only shrink: the newest level whose counters have arrived bounds every later one
-                pl.maxdeg_bound = maxdeg1;
-                const int k = l - 1 - lookahead;
-                if (k >= 1 && e->hgate[k].seq == run_seq && e->hgate[k].active) pl.maxdeg_bound = std::min(maxdeg1, e->hgate[k].maxdeg);
-                pl.staged_classes = staged_classes;
-            }
             pl.use_fast = (e->opt_fast != 0) && (l >= 2) && !pl.force_exact;
             // 2. the neighbour lists (no host dependency)
             CUSK_HIP(e, launch_fill_nbr(e->adj.as<unsigned long long>(), off_l, e->nbr[cs].as<int>(),
                                         (a.mode == 0 && !pl.use_rows) ? e->best[cs].as<unsigned long long>() : nullptr, n, words,
                                         (l == 1 && (pl.use_rows || a.mode == 0)) ? e->wpre.as<int>() : nullptr, dcnt + l, a.row_range, s));
+            // Level 2 is the level at which the degrees collapse (on LD data level 1 removes nine edges in ten): the host
+            // looks at its gate record -- which travels while the device compacts the lists just enqueued -- and knows the
+            // level's class counts and a degree bound for every later level.  Without it the stale level-1 bound made
+            // levels 2-4 fork their sweeps over degree classes that turn out empty (an event fork / join per level, ~20 us).
+            if (l == 2 && !sharded && e->opt_sync2)
+            {
+                const int rc2 = wait_gate(2);
+                if (rc2 != CUSK_OK) return rc2;
+                if (!e->hgate[2].active) break;
+                for (int c = 0; c < kNumClasses; c++) pl.nitems[c] = e->hgate[2].class_items[c];
+                pl.known_items = !e->hgate[2].item_overflow;
+                maxdeg2 = e->hgate[2].maxdeg;
+            }
+            {  // degrees only shrink: the newest level whose counters have arrived bounds every later one
+                pl.maxdeg_bound = maxdeg1;
+                if (maxdeg2 >= 0 && l >= 2) pl.maxdeg_bound = std::min(pl.maxdeg_bound, maxdeg2);
+                const int k = l - 1 - lookahead;
+                if (k >= 1 && e->hgate[k].seq == run_seq && e->hgate[k].active) pl.maxdeg_bound = std::min(pl.maxdeg_bound, e->hgate[k].maxdeg);
+                pl.staged_classes = staged_classes;
+            }
 
             SweepParams &sp = pl.sp;
             sp.C = a.C;
@@ -659,8 +680,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         hp_mark("all_enq");
         CUSK_HIP(e, hipStreamSynchronize(s));
         hp_mark("synced");
-        int ended = 0;  // first level whose gate stayed closed
-        for (int l = 1; l <= enq_last && !ended; l++)
+        int ended = 0;  // first level whose gate stayed closed (a level whose plan ran but whose sweeps were not enqueued included)
+        for (int l = 1; l <= planned_last && !ended; l++)
             if (!e->hcnt[l].active) ended = l;
         const int last_ran = ended ? ended - 1 : enq_last;
         // a recheck queue that overflowed: that level was not finalised and nothing after it ran
@@ -700,6 +721,7 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
         }
         // resume: the counters of the levels that are enqueued again start from zero, their gate records are void
         for (int l = start; l < kLevels; l++) e->hgate[l].seq = 0;
+        if (start <= 2) maxdeg2 = -1;
         if (start <= last_level)
         {
             CUSK_HIP(e, hipMemsetAsync(dcnt + start, 0, sizeof(LevelCounters) * (size_t)(kLevels - start), s));
@@ -956,6 +978,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_timing = (int)value;
     else if (k == "l1_exp")
         e->opt_l1_exp = (int)value;
+    else if (k == "sync2")
+        e->opt_sync2 = (int)value;
     else if (k == "sepselect_ws_bytes" && value > 0)
         e->opt_sep_ws_budget = value;
     else

@@ -271,7 +271,7 @@ hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, un
 // elsewhere, written to adj and adj0; also the level-1 degrees
 hipError_t launch_level0_batch(const float *C, unsigned long long *adj, unsigned long long *adj0, int *deg, int n, int words,
                                const int2 *row_range, float th, hipStream_t st);
-hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st);
+hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, unsigned long long *adj0, hipStream_t st);
 hipError_t launch_fill_nbr(const unsigned long long *adj, const int *off, int *nbr, unsigned long long *best, int n, int words,
                            int *wpre, const LevelCounters *cnt, const int2 *row_range, hipStream_t st);
 // The level's plan from the degrees alone: CSR offsets, the work items of every degree class (written straight into the

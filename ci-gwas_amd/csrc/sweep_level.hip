@@ -385,20 +385,26 @@ hipError_t launch_level0_batch(const float *C, unsigned long long *adj, unsigned
 // compaction: bitmap -> CSR neighbour lists + work list
 // ---------------------------------------------------------------------------
 
-__global__ void degree_kernel(const unsigned long long *__restrict__ adj, int *deg, int n, int words)
+// degrees after level 0; the same pass leaves the level-0 copy of the bitmap (adj0: record slots, pMax) when asked to
+__global__ void degree_kernel(const unsigned long long *__restrict__ adj, int *deg, int n, int words, unsigned long long *adj0)
 {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= n) return;
     int d = 0;
-    for (int w = lane; w < words; w += 64) d += __popcll(adj[(size_t)row * words + w]);
+    for (int w = lane; w < words; w += 64)
+    {
+        const unsigned long long v = adj[(size_t)row * words + w];
+        if (adj0) adj0[(size_t)row * words + w] = v;
+        d += __popcll(v);
+    }
     for (int o = 32; o > 0; o >>= 1) d += __shfl_xor(d, o);
     if (lane == 0) deg[row] = d;
 }
 
-hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, hipStream_t st)
+hipError_t launch_degree(const unsigned long long *adj, int *deg, int n, int words, unsigned long long *adj0, hipStream_t st)
 {
-    hipLaunchKernelGGL(degree_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, deg, n, words);
+    hipLaunchKernelGGL(degree_kernel, dim3((n + 3) / 4), dim3(256), 0, st, adj, deg, n, words, adj0);
     return hipGetLastError();
 }
 
