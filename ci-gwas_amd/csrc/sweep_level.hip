@@ -517,7 +517,7 @@ constexpr unsigned long long kPlanMask = (1ull << 40) - 1ull;
 
 __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
 {
-    __shared__ int s_wave[kNumClasses][4];
+    __shared__ long long s_wave[kNumClasses][4];  // (64-bit: 64 hub rows of a deep level can hold more than 2^31 items together)
     __shared__ int s_wdeg[4], s_wmax[4];
     __shared__ long long s_part[4][kPlanWords];
     __shared__ long long s_base[kNumClasses];
@@ -606,15 +606,15 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
     for (int o = 32; o > 0; o >>= 1) dmax = max(dmax, __shfl_xor(dmax, o));
     if (lane == 63) s_wdeg[wave] = dincl;
     if (lane == 0) s_wmax[wave] = dmax | (wave_ovf ? (1 << 30) : 0);  // bit 30: a row's C(d, l) does not fit 62 bits
-    int excl[kNumClasses];
+    long long excl[kNumClasses];
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
     {
-        const int mine = (cls == c) ? nchunks : 0;
-        int v = mine;
+        const long long mine = (cls == c) ? nchunks : 0;
+        long long v = mine;
         for (int o = 1; o < 64; o <<= 1)
         {
-            const int t = __shfl_up(v, o);
+            const long long t = __shfl_up(v, o);
             if (lane >= o) v += t;
         }
         excl[c] = v - mine;
@@ -630,7 +630,7 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
         if (tid == 0)
             v = (unsigned long long)((long long)s_wdeg[0] + s_wdeg[1] + s_wdeg[2] + s_wdeg[3]);
         else if (tid <= kNumClasses)
-            v = (unsigned long long)((long long)s_wave[tid - 1][0] + s_wave[tid - 1][1] + s_wave[tid - 1][2] + s_wave[tid - 1][3]);
+            v = (unsigned long long)(s_wave[tid - 1][0] + s_wave[tid - 1][1] + s_wave[tid - 1][2] + s_wave[tid - 1][3]);
         else if (tid == 6)
             v = (unsigned long long)(max(max(s_wmax[0], s_wmax[1]), max(s_wmax[2], s_wmax[3])) & ~(1 << 30));
         else if (tid == 7)
@@ -676,7 +676,7 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
 #pragma unroll
     for (int c = 0; c < kNumClasses; c++)
     {
-        const long long mine = (long long)s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
+        const long long mine = s_wave[c][0] + s_wave[c][1] + s_wave[c][2] + s_wave[c][3];
         tot_items[c] = before[1 + c] + mine;  // through this block (the last block: the level's total)
         if (tid == c) s_base[c] = (tot_items[c] > a.item_cap) ? -1 : before[1 + c];  // would not fit: the host grows the buffers
     }
@@ -685,14 +685,14 @@ __global__ void __launch_bounds__(256) plan_kernel(PlanArgs a)
     {
         int pos = -1;
         if (cls >= 0 && s_base[cls] >= 0)
-        {
-            int add = 0;
+        {  // (the class total fits the buffer here, so every position does)
+            long long add = 0;
             for (int w = 0; w < wave; w++) add += s_wave[cls][w];
-            int e = 0;
+            long long e = 0;
 #pragma unroll
             for (int c = 0; c < kNumClasses; c++)
                 if (cls == c) e = excl[c];
-            pos = (int)s_base[cls] + add + e;
+            pos = (int)(s_base[cls] + add + e);
         }
         // rows with a single item write it themselves; the few rows with several (hubs: hundreds) are handled by the
         // whole workgroup, found through ballots instead of a walk over all 256 rows

@@ -219,18 +219,22 @@ class _Queue:
             return self.order[self.pos] if self.pos < len(self.order) else -1
 
 
-def run_rank_batched(bs, queue: "_Queue", device: int, batch_vars: int, options: dict | None = None, write_dir: str | None = None):
+def run_rank_batched(bs, queue: "_Queue", device: int, batch_vars: int, options: dict | None = None, write_dir: str | None = None,
+                     engine_factory=None):
     """The rank's blocks in batches of at most `batch_vars` padded variables, each batch through cusk_blockset_run_batch
     (one level loop per stage for the whole batch).  -> (list of BatchResult, list of CuskBatchStats).  write_dir: the
     files of a batch are written (by the library, cusk_batch_result_write) on a thread of their own beside the next batch."""
-    cache = bs._engines.setdefault(device, [])
-    if not cache:
-        cache.append(Engine(device))
-    eng = cache[0]
+    if engine_factory is not None:  # CPU tests of the batching / gather logic with a stand-in block set
+        eng = engine_factory()
+    else:
+        cache = bs._engines.setdefault(device, [])
+        if not cache:
+            cache.append(Engine(device))
+        eng = cache[0]
     for k, v in (options or {}).items():
         if k != "corr_ahead":
             eng.set_option(k, int(v))
-    if not bs.stage(eng):
+    if engine_factory is None and not bs.stage(eng):
         raise RuntimeError("batched runs need the block set's inputs on the device (cusk_blockset_stage failed)")
     def batches():
         """batches drawn from the queue as they are needed (with the shared counter of the dynamic schedule a rank must not
@@ -298,17 +302,20 @@ def gather_packed(payload: np.ndarray, device=None, group=None):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     dev = device if device is not None else "cpu"
     size = torch.tensor([payload.size], dtype=torch.int64, device=dev)
-    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, size, group=group)
-    cap = max(1, int(max(int(s.item()) for s in sizes)))
+    sizes = torch.zeros(world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(sizes, size, group=group)
+    sizes = [int(v) for v in sizes.cpu()]
+    cap = max(1, max(sizes))
     mine = torch.zeros(cap, dtype=torch.uint8, device=dev)
     if payload.size:
         mine[: payload.size] = torch.from_numpy(payload).to(dev)
-    bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-    dist.all_gather(bufs, mine, group=group)
+    # a GATHER, not an all-gather: only rank 0 needs the results (over RCCL: grouped send / recv into rank 0, each byte
+    # crosses one xGMI link once)
+    bufs = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)] if rank == 0 else None
+    dist.gather(mine, bufs, dst=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     if rank != 0:
         return None
-    return [bufs[r][: int(sizes[r].item())].cpu().numpy() for r in range(world)]
+    return [bufs[r][: sizes[r]].cpu().numpy() for r in range(world)]
 
 
 def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | None = None, engine_factory=None,
@@ -417,12 +424,13 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
     else:
         owned = shard.assign_blocks(costs, world)[rank]
         queue = _Queue(sorted(owned, key=lambda b: (-costs[b], b)))  # big blocks first within the rank as well
-    if batch_vars > 0 and engine_factory is None:
+    if batch_vars > 0 and hasattr(bs, "run_batch"):
         # batched execution: the rank's blocks in batches, one level loop per stage and batch.  Returns the block indices
         # that were written (all of the job's on rank 0 with writer = rank0, the rank's own with writer = local), the
         # per-batch stats, and the assignment
         t0 = time.perf_counter()
-        bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer == "local" else None)
+        bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer == "local" else None,
+                                        engine_factory=engine_factory)
         done = sorted(b for r in bres for b in r.block_indices)
         t1 = time.perf_counter()
         if writer == "local":

@@ -56,6 +56,87 @@ class _OracleBlockSet:
         return shard.BlockResult(b, f"1_{b}_{b}", 4, red.max_level, red.new_to_old, red.G, red.C, red.S), _Stats(0)
 
 
+class _OracleBatch:
+    """stand-in for run_blocks.BatchResult: the results of a batch, computed by the oracle block by block"""
+
+    def __init__(self, results):
+        self._r = results
+        self.block_indices = [r.block_index for r in results]
+
+    def pack(self):
+        return np.concatenate([r.pack() for r in self._r]) if self._r else np.zeros(0, np.uint8)
+
+    def write(self, outdir):
+        for r in self._r:
+            r.write(outdir)
+
+    def free(self):
+        pass
+
+
+class _BatchStats:
+    def __init__(self, blocks, skipped):
+        self.blocks, self.skipped, self.tests = blocks, skipped, [1, 1]
+
+
+class _OracleBatchSet(_OracleBlockSet):
+    def run_batch(self, eng, blocks):
+        res = [self.run_block(eng, b)[0] for b in blocks]
+        return _OracleBatch([r for r in res if r is not None]), _BatchStats(len(blocks), sum(r is None for r in res))
+
+
+def _batch_worker(rank, world, port, outdir, mode, q):
+    import sys
+
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from cigwas_amd import run_blocks as rb
+
+    schedule, writer, bv = mode.split("+")
+    tm = {}
+    done, stats, owned = rb.run_job(_OracleBatchSet(), outdir, device=0, schedule=schedule, engine_factory=_NoEngine,
+                                    store_key=f"nextb_{mode}", writer=writer, batch_vars=int(bv), timings=tm)
+    if writer == "rank0":
+        assert (done is None) == (rank != 0) and "gather_s" in tm
+        if rank == 0:
+            assert done == [b for b in range(NBLOCKS) if b != 3]
+    q.put((rank, sum(s_.blocks for s_ in stats), len(stats)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+@pytest.mark.parametrize("mode", ["lpt+rank0+300", "dynamic+rank0+200", "lpt+local+100000"])
+def test_two_rank_batched_job_gathers_packed_results(tmp_path, oracle, synth, mode):
+    """the batched job path (run_blocks.run_job with batch_vars > 0) over gloo: batches cut from the rank's queue, ONE gather
+    of the packed results to rank 0, files written by the library's packed writer (host code of libcusk_hip.so)"""
+    import torch.multiprocessing as mp
+
+    out = tmp_path / "o"
+    out.mkdir()
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    mp.spawn(_batch_worker, args=(2, _free_port(), str(out), mode, q), nprocs=2, join=True)
+    got = [q.get() for _ in range(2)]
+    assert sum(g[1] for g in got) == NBLOCKS  # every block in exactly one batch of one rank
+    if mode.endswith("+100000"):
+        assert all(g[2] <= 1 for g in got)  # one batch per rank
+    else:
+        assert sum(g[2] for g in got) >= 3
+    stems = sorted({f.rsplit(".", 1)[0] for f in os.listdir(out)})
+    assert stems == [f"1_{b}_{b}" for b in range(NBLOCKS) if b != 3]
+    for b in (1, 5):
+        Cm = synth.synth_corr_block(SIZES[b], 4, N=2000, block_index=b)
+        red = oracle.cusk_from_corr(Cm, 4, oracle.threshold_array(2000, 1e-3), 2, 3, 1)
+        oracle.write_reduced(red, str(tmp_path / f"ref_{b}"), with_sep=True)
+        for ext in (".mdim", ".ixs", ".adj", ".corr", ".sep"):
+            assert open(str(out / f"1_{b}_{b}") + ext, "rb").read() == open(str(tmp_path / f"ref_{b}") + ext, "rb").read()
+
+
 def _worker(rank, world, port, outdir, schedule, q):
     import sys
 
