@@ -147,7 +147,10 @@ __global__ void __launch_bounds__(kExactThreads) recheck_kernel(SweepParams p)
     extern __shared__ __attribute__((aligned(16))) float ws_lds[];
     const unsigned long long count = min(p.cnt->qcount, p.qcap);
     const int n = p.n;
-    for (unsigned long long e = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; e < count;
+    // Entries go to WORKGROUPS first, to the lanes of a workgroup only when there are more entries than workgroups: the
+    // deep levels queue a few dozen tests, and 33 of them side by side in one wavefront run the data-dependent loops of the
+    // SVD in lockstep (the wave executes the union of every lane's path); one entry per wave is one undisturbed chain
+    for (unsigned long long e = (unsigned long long)blockIdx.x + (unsigned long long)gridDim.x * threadIdx.x; e < count;
          e += (unsigned long long)gridDim.x * blockDim.x)
     {
         const RecheckEntry en = p.queue[e];
