@@ -95,6 +95,8 @@ SYMBOLS = {
     "cusk_run_hetcor": (_i, [_vp, _vp, _vp, _f, _vp, _i, _f, _i, _vp, C.POINTER(CuskStats)]),
     "cusk_run_skeleton_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, C.POINTER(CuskStats)]),
     "cusk_result_adj_bits_blocks": (_i, [_vp, _vp]),
+    "cusk_result_adj_bits_blocks_tail": (_i, [_vp, _i, _vp]),
+    "cusk_result_adj_rows": (_i, [_vp, _i, _i, _vp]),
     "cusk_gather_rows": (_i, [_vp, _vp, _i, _vp, _ll, _vp, _vp, _vp, _vp, _ll, _vp, _ll, _i]),
     "cusk_result_n": (_i, [_vp]),
     "cusk_result_adj_bits_dev": (_vp, [_vp]),

@@ -1100,18 +1100,51 @@ extern "C" int cusk_run_skeleton_batch(cusk_engine *e, const float *C_dev, int n
 
 // the adjacency of the last batched run, block by block: rows lo..hi-1 of block b, each as the (hi - lo + 63) / 64 words of
 // the block's own columns (bit j = local variable j; bases are multiples of 64), blocks back to back
-extern "C" int cusk_result_adj_bits_blocks(cusk_engine *e, uint64_t *out_host)
+static int pack_blocks(cusk_engine *e, uint64_t *out_host, int tail)
 {
-    if (!e || !e->have_result || e->batch_lo.empty() || !out_host) return fail(e, CUSK_ERR_STATE, "no batched result");
+    if (!e || !e->have_result || e->batch_lo.empty() || !out_host || tail < 0) return fail(e, CUSK_ERR_STATE, "no batched result");
     CUSK_HIP(e, hipSetDevice(e->device));
+    const size_t nblk = e->batch_lo.size();
+    std::vector<long long> woff(nblk);
     long long total = 0;
-    for (size_t b = 0; b < e->batch_lo.size(); b++)
-        total += (long long)(e->batch_hi[b] - e->batch_lo[b]) * ((e->batch_hi[b] - e->batch_lo[b] + 63) / 64);
+    for (size_t b = 0; b < nblk; b++)
+    {
+        const int k = e->batch_hi[b] - e->batch_lo[b];
+        woff[b] = total;
+        total += (long long)(tail > 0 ? std::min(tail, k) : k) * ((k + 63) / 64);
+    }
     if (total == 0) return CUSK_OK;
     CUSK_HIP(e, e->scratch_b.ensure(sizeof(unsigned long long) * (size_t)total));
+    const long long *woff_d = e->blk_woff.as<long long>();  // the full packing's offsets were uploaded with the run
+    if (tail > 0)
+    {
+        CUSK_HIP(e, e->scratch_a.ensure(sizeof(long long) * nblk));
+        CUSK_HIP(e, hipMemcpyAsync(e->scratch_a.p, woff.data(), sizeof(long long) * nblk, hipMemcpyHostToDevice, e->stream));
+        woff_d = e->scratch_a.as<long long>();
+    }
     CUSK_HIP(e, launch_pack_block_bits(e->adj.as<unsigned long long>(), e->n, e->words, e->row_range.as<int2>(), e->row_blk.as<int>(),
-                                       e->blk_woff.as<long long>(), e->scratch_b.as<unsigned long long>(), e->stream));
+                                       woff_d, e->scratch_b.as<unsigned long long>(), tail, e->stream));
     CUSK_HIP(e, hipMemcpyAsync(out_host, e->scratch_b.p, sizeof(unsigned long long) * (size_t)total, hipMemcpyDeviceToHost, e->stream));
+    CUSK_HIP(e, hipStreamSynchronize(e->stream));  // (also covers the copy out of `woff`)
+    return CUSK_OK;
+}
+
+extern "C" int cusk_result_adj_bits_blocks(cusk_engine *e, uint64_t *out_host) { return pack_blocks(e, out_host, 0); }
+extern "C" int cusk_result_adj_bits_blocks_tail(cusk_engine *e, int tail_rows, uint64_t *out_host)
+{
+    if (tail_rows <= 0) return fail(e, CUSK_ERR_ARG, "tail_rows must be positive");
+    return pack_blocks(e, out_host, tail_rows);
+}
+
+// rows [row0, row0 + nrows) of the last run's adjacency bitmap (cusk_result_words() words each): what the pruning of depth 1
+// needs of a 10k-variable block are its trait rows, 25 KB instead of the 12.6 MB bitmap
+extern "C" int cusk_result_adj_rows(cusk_engine *e, int row0, int nrows, uint64_t *out_host)
+{
+    if (!e || !e->have_result || !out_host || row0 < 0 || nrows < 0 || row0 + nrows > e->n) return fail(e, CUSK_ERR_ARG, "bad rows");
+    if (nrows == 0) return CUSK_OK;
+    CUSK_HIP(e, hipSetDevice(e->device));
+    CUSK_HIP(e, hipMemcpyAsync(out_host, e->adj.as<unsigned long long>() + (size_t)row0 * e->words,
+                               sizeof(unsigned long long) * (size_t)nrows * e->words, hipMemcpyDeviceToHost, e->stream));
     CUSK_HIP(e, hipStreamSynchronize(e->stream));
     return CUSK_OK;
 }

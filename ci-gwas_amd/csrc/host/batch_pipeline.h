@@ -117,27 +117,11 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     std::vector<unsigned char> keep((size_t)B, 0);
     std::vector<int> kept;
     {
-        const double c_lo = std::tanh((double)in.Th[0]) * (1.0 - 1e-6), c_hi = std::tanh((double)in.Th[0]) * (1.0 + 1e-6);
         size_t o = 0;
         for (int b = 0; b < B; b++)
         {
-            int num_sig = 0;
             const size_t cnt = (size_t)m[(size_t)b] * p;
-            for (size_t i = 0; i < cnt; i++)
-            {
-                // |atanh c| >= Th[0] is a comparison of |c| with tanh(Th[0]): only the elements within 1e-6 (relative) of
-                // that value, NaN and |c| >= 1 go through the reference's expression (cli.cpp:561-565) -- the two logs cost
-                // 1 ms per 14,000 markers x 20 traits otherwise
-                const float c = mxp[o + i];
-                const double ac = std::fabs((double)c);
-                if (ac < c_lo) continue;
-                if (ac > c_hi && ac < 1.0)
-                {
-                    num_sig++;
-                    continue;
-                }
-                num_sig += (std::fabs(0.5 * (std::log(std::fabs((1 + c))) - std::log(std::fabs(1 - c)))) >= in.Th[0]);
-            }
+            const int num_sig = count_significant(mxp.data() + o, cnt, in.Th[0]);
             o += cnt;
             outs[(size_t)b].num_sig = num_sig;
             outs[(size_t)b].skipped = (num_sig == 0);
@@ -180,11 +164,14 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
 
     // ---- prune (parent_set.cpp:8-53 per block) and the stage-two matrices (cli.cpp:62-87), gathered device to device ----
     std::vector<uint64_t> packed;
+    const bool traits_only = (in.depth == 1 && p > 0);  // depth 1 looks at the trait rows only
     {
         size_t words = 0;
-        for (int k = 0; k < K; k++) words += (size_t)(hi1[(size_t)k] - lo1[(size_t)k]) * (size_t)((hi1[(size_t)k] - lo1[(size_t)k] + 63) / 64);
+        for (int k = 0; k < K; k++)
+            words += (size_t)(traits_only ? (int)p : hi1[(size_t)k] - lo1[(size_t)k]) * (size_t)((hi1[(size_t)k] - lo1[(size_t)k] + 63) / 64);
         packed.resize(words);
-        if (cusk_result_adj_bits_blocks(e, packed.data()) != CUSK_OK) engine_die("adjacency (batch)", e);
+        if ((traits_only ? cusk_result_adj_bits_blocks_tail(e, (int)p, packed.data()) : cusk_result_adj_bits_blocks(e, packed.data())) != CUSK_OK)
+            engine_die("adjacency (batch)", e);
     }
     mark("bits1");
     std::vector<std::vector<int>> P1((size_t)K);
@@ -195,8 +182,20 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
         for (int k = 0; k < K; k++)
         {
             const int nb = hi1[(size_t)k] - lo1[(size_t)k];
-            const Bits G = block_bits(packed, pos, nb);
-            P1[(size_t)k] = subset_variables(G, nb, nb - (int)p, in.depth);
+            if (traits_only)
+            {
+                Bits T;
+                T.n = (int)p;
+                T.words = (nb + 63) / 64;
+                T.w.assign(packed.begin() + (long)pos, packed.begin() + (long)(pos + (size_t)T.n * T.words));
+                pos += (size_t)T.n * T.words;
+                P1[(size_t)k] = subset_variables_depth1(T, nb, nb - (int)p);
+            }
+            else
+            {
+                const Bits G = block_bits(packed, pos, nb);
+                P1[(size_t)k] = subset_variables(G, nb, nb - (int)p, in.depth);
+            }
             lo2[(size_t)k] = (int)n2;
             hi2[(size_t)k] = (int)n2 + (int)P1[(size_t)k].size();
             n2 += (size_t)pad64(P1[(size_t)k].size());

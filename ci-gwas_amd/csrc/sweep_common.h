@@ -313,7 +313,7 @@ hipError_t launch_gather_sub(const float *M, int n, const int *idx, int k, float
 hipError_t launch_gather_rows(const float *M, int n, const int *idx, const int *row_src, const int *row_k, const long long *row_first,
                               const long long *row_out, long long nrows, float *out, hipStream_t st);
 hipError_t launch_pack_block_bits(const unsigned long long *adj, int n, int words, const int2 *row_range, const int *row_blk,
-                                  const long long *blk_woff, unsigned long long *out, hipStream_t st);
+                                  const long long *blk_woff, unsigned long long *out, int tail, hipStream_t st);
 hipError_t launch_expand_adj(const unsigned long long *adj, int *G, int n, int words, hipStream_t st);
 hipError_t launch_expand_pmax(const unsigned long long *adj, const unsigned long long *adj0, const float *C, float *pmax,
                               int n, int words, const int *x, const int *y, const float *z, long long nrec, hipStream_t st);

@@ -1982,9 +1982,11 @@ hipError_t launch_gather_rows(const float *M, int n, const int *idx, const int *
 }
 
 // batched runs: the bitmap rows of every block, cut to the block's own words, packed back to back
+// tail > 0: only the last `tail` rows of every block (the traits: all the pruning of depth 1 looks at)
 __global__ void __launch_bounds__(256) pack_block_bits_kernel(const unsigned long long *__restrict__ adj, int n, int words,
                                                                const int2 *__restrict__ row_range, const int *__restrict__ row_blk,
-                                                               const long long *__restrict__ blk_woff, unsigned long long *out)
+                                                               const long long *__restrict__ blk_woff, unsigned long long *out,
+                                                               int tail)
 {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
@@ -1992,16 +1994,18 @@ __global__ void __launch_bounds__(256) pack_block_bits_kernel(const unsigned lon
     const int b = row_blk[row];
     if (b < 0) return;
     const int2 rg = row_range[row];
+    const int first = (tail > 0) ? max(rg.x, rg.y - tail) : rg.x;
+    if (row < first) return;
     const int wb = (rg.y - rg.x + 63) >> 6, w0 = rg.x >> 6;
-    unsigned long long *dst = out + blk_woff[b] + (long long)(row - rg.x) * wb;
+    unsigned long long *dst = out + blk_woff[b] + (long long)(row - first) * wb;
     for (int w = lane; w < wb; w += 64) dst[w] = adj[(size_t)row * words + w0 + w];
 }
 
 hipError_t launch_pack_block_bits(const unsigned long long *adj, int n, int words, const int2 *row_range, const int *row_blk,
-                                  const long long *blk_woff, unsigned long long *out, hipStream_t st)
+                                  const long long *blk_woff, unsigned long long *out, int tail, hipStream_t st)
 {
     hipLaunchKernelGGL(pack_block_bits_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, adj, n, words, row_range, row_blk,
-                       blk_woff, out);
+                       blk_woff, out, tail);
     return hipGetLastError();
 }
 

@@ -127,7 +127,7 @@ const char *cusk_last_error(const cusk_engine *e);
  * classes and the winners' exact z run on an auxiliary stream), "corr_fp4" (default 1: the SNP x SNP contingency GEMMs of
  * cusk_corr_build on the FP4 matrix pipe; 0: the int8 MFMA form), "corr_popcount" (default 0; 1: bit-plane AND/popcount
  * cross-check kernels instead of the matrix cores), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
- * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (HIP events for cusk_stats: 0 total_ms only; 1, the default, around every level's sweep: kernel_ms, and level_ms = end of the previous level's sweep to the end of this one's; 2 also level start / end: level_ms = plan to finaliser; 3 only the pair around the level-1 row kernel: main_kernel_ms[1] -- every event costs a few microseconds of device time), "chunk0" (conditioning sets per work item of the first degree class, default 512), "tmaj_min_level" (first level swept by unions T = S + Y, one inverse per l + 1 tests: default 6, 99 = never; single threshold and symmetric matrix only), "tmaj_validate_stride" (with "validate": the union-major sweep checks the unions whose per-lane count is a multiple of this power of two against double precision; default 1 = all), "hostprof" (1: host-side phase marks of every run on stderr), "max_staged_classes" (test hook: at most this many degree classes keep their sub-matrix in LDS; 0 sends every row through the kernels of the unstaged class), "chunk0_low" (work-item size of the first degree class at levels 2-4, default 256), "vec_threads" (workgroup size of the vectorised sweep for the first degree class: 64, 128 or 256; default 64), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
+ * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (HIP events for cusk_stats: 0 total_ms only; 1, the default, around every level's sweep: kernel_ms, and level_ms = end of the previous level's sweep to the end of this one's; 2 also level start / end: level_ms = plan to finaliser; 3 only the pair around the level-1 row kernel: main_kernel_ms[1] -- every event costs a few microseconds of device time), "chunk0" (conditioning sets per work item of the first degree class, default 512), "tmaj_min_level" (first level swept by unions T = S + Y, one inverse per l + 1 tests: default 6, 99 = never; single threshold and symmetric matrix only), "tmaj_validate_stride" (with "validate": the union-major sweep checks the unions whose per-lane count is a multiple of this power of two against double precision; default 1 = all), "hostprof" (1: host-side phase marks of every run on stderr), "max_staged_classes" (test hook: at most this many degree classes keep their sub-matrix in LDS; 0 sends every row through the kernels of the unstaged class), "chunk0_low" (work-item size of the first degree class at levels 2-4, default 256), "vec_threads" (workgroup size of the vectorised sweep for the first degree class: 64, 128 or 256; default 64), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "sync2" (default 1: the host reads level 2's gate record -- class counts, maximum degree -- before it enqueues that level's sweeps, so that degree classes that turn out empty are not launched at levels >= 2; 0: enqueue ahead on the level-1 degree bound), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
  * cusk_sepselect_greedy for candidate lists too long for LDS, default 4 GiB; such pairs run in batches of what fits). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);
 void *cusk_engine_stream(const cusk_engine *e);
@@ -187,6 +187,11 @@ int cusk_run_skeleton_batch(cusk_engine *e, const float *C_dev, int n, int nblk,
  * words of the block's own columns (bit j of a row = local variable j), blocks back to back.  out_host: room for
  * sum_b (hi[b] - lo[b]) * ((hi[b] - lo[b] + 63) / 64) words. */
 int cusk_result_adj_bits_blocks(cusk_engine *e, uint64_t *out_host);
+/* the same for the LAST tail_rows rows of every block only (the traits: parent_set.cpp:8-53 at depth 1 looks at nothing
+ * else); a block with fewer rows gives all of them */
+int cusk_result_adj_bits_blocks_tail(cusk_engine *e, int tail_rows, uint64_t *out_host);
+/* rows [row0, row0 + nrows) of the last run's bitmap, cusk_result_words() words each, to host memory */
+int cusk_result_adj_rows(cusk_engine *e, int row0, int nrows, uint64_t *out_host);
 /* Many sub-matrices in one launch: out[row_out[t] + c] = M_dev[row_src[t] * n + idx[row_first[t] + c]] for c < row_k[t],
  * t < nrows (parent_set.cpp:84-238 for a batch: the stage-two matrices straight onto the diagonal of the next batch
  * allocation, out_on_device = 1; the retained sub-matrices of the results, out_on_device = 0, out_count floats).  Index

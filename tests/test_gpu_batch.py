@@ -219,3 +219,39 @@ def test_two_ranks_batched_over_gloo(chromosome, tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=800)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     _same_files(str(chromosome["ref"]), str(out))
+
+
+def test_depth_two_batch_equals_per_block_and_oracle(chromosome, oracle):
+    """max_depth 2 takes the general pruning (the whole bitmap of a block travels; depth 1 reads the trait rows only):
+    batched and per-block execution agree with each other and, for one block, with the oracle pipeline"""
+    from cigwas_amd import run_blocks as rb
+    from cigwas_amd.skeleton import Engine
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), 2)
+    e = Engine(0)
+    sig = chromosome["signal"][:3]
+    br, _st = bs.run_batch(e, sig)
+    res = {r.block_index: r for r in br.results()}
+    for b in sig:
+        one, _ = bs.run_block(e, b)
+        r = res[b]
+        assert np.array_equal(r.new_to_old, one.new_to_old) and np.array_equal(r.adj, one.adj)
+        assert np.array_equal(r.corr, one.corr) and np.array_equal(r.sep, one.sep)
+    b = sig[0]
+    cid, f, l, g0 = chromosome["bounds"][b]
+    mb, N, p = l - f + 1, chromosome["N"], chromosome["p"]
+    bed = np.fromfile(chromosome["stem"] + ".bed", np.uint8)[3:].reshape(-1, (N + 3) // 4)
+    means = np.loadtxt(chromosome["stem"] + ".means", dtype=np.float32)
+    stds = np.loadtxt(chromosome["stem"] + ".stds", dtype=np.float32)
+    phen = oracle.load_phen(chromosome["phen"])[2]
+    sel = slice(g0, g0 + mb)
+    o_mxm, o_mxp, o_pxp = oracle.corr_pearson_npn(bed[sel], phen, mb, N, p, means[sel], stds[sel])
+    ref = oracle.cusk_from_corr(oracle.square_from_cusk_corrs(o_mxm, o_mxp, o_pxp, mb, p), p, oracle.threshold_array(N, float(ALPHA)),
+                                int(L1), int(L2), 2)
+    assert list(res[b].new_to_old) == list(ref.new_to_old)
+    assert np.array_equal(res[b].adj.reshape(-1), np.asarray(ref.G, np.int32).reshape(-1))
+    assert np.array_equal(res[b].sep.reshape(-1), np.asarray(ref.S, np.int32).reshape(-1))
+    br.free()
+    rb.lib().cusk_blockset_release_engine(bs.h, e.h)
+    e.close()
+    bs.close()
