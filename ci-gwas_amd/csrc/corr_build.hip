@@ -1168,7 +1168,7 @@ __global__ void __launch_bounds__(256) batch_finish_kernel(float *C, size_t n, c
 // stream (the sweep that follows is ordered behind it).
 int corr_build_batch_impl(cusk_engine *e, int phase, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
                           const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker, const int *markers,
-                          const int *base, const unsigned char *keep, size_t n, float *C_dev, float *mxp_host)
+                          const int *base, const unsigned char *keep, size_t n, float *C_dev, float *mxp_host, bool async_mxp = false)
 {
     if (!e || !bed_dev || !phen_dev || !mean_dev || !std_dev || !first_marker || !markers || !base || !C_dev || nblk <= 0 || N == 0)
         return fail(e, CUSK_ERR_ARG, "bad arguments");
@@ -1257,6 +1257,23 @@ int corr_build_batch_impl(cusk_engine *e, int phase, const unsigned char *bed_de
                                    mean_dev, std_dev, C_dev, mxp_d, (size_t)0, N, p, clb, n, p0, (int)pc, mt_d, blk_d);
         }
         CUSK_HIP(e, hipGetLastError());
+        if (async_mxp)
+        {  // cusk_corr_build_batch: the correlations land in pinned memory, an event marks their arrival, nobody waits here
+            const size_t cnt = (size_t)moff * p;
+            if (cnt > e->mxp_pinned_cap)
+            {
+                if (e->mxp_pending) return fail(e, CUSK_ERR_STATE, "a correlation build is in flight");
+                if (e->mxp_pinned) (void)hipHostFree(e->mxp_pinned);
+                e->mxp_pinned = nullptr;
+                e->mxp_pinned_cap = 0;
+                CUSK_HIP(e, hipHostMalloc(reinterpret_cast<void **>(&e->mxp_pinned), sizeof(float) * (cnt + cnt / 4 + 64)));
+                e->mxp_pinned_cap = cnt + cnt / 4 + 64;
+            }
+            if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(e->mxp_pinned, mxp_d, sizeof(float) * cnt, hipMemcpyDeviceToHost, s));
+            if (!e->ev_mxp) CUSK_HIP(e, hipEventCreateWithFlags(&e->ev_mxp, hipEventDisableTiming));
+            CUSK_HIP(e, hipEventRecord(e->ev_mxp, s));
+            return CUSK_OK;
+        }
         if (mxp_d) CUSK_HIP(e, hipMemcpyAsync(mxp_host, mxp_d, sizeof(float) * (size_t)moff * p, hipMemcpyDeviceToHost, s));
         CUSK_HIP(e, hipStreamSynchronize(s));
         return CUSK_OK;
@@ -1404,6 +1421,28 @@ extern "C" int cusk_corr_build_batch_mxm(cusk_engine *e, const unsigned char *be
 {
     return corr_build_batch_impl(e, 2, bed_dev, phen_dev, mean_dev, std_dev, N, p, nblk, first_marker, markers, base, keep, (size_t)n,
                                  C_dev, nullptr);
+}
+
+// Everything in one call, the marker x marker part speculatively for EVERY block: the host's prefilter (cli.cpp:561-576)
+// then runs beside the contingency GEMMs instead of between two synchronisations (a block that is skipped after all had
+// its matrix built for nothing: rare -- one false positive among its m x p marginal tests is enough to keep it)
+extern "C" int cusk_corr_build_batch(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                                     const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                                     const int *markers, const int *base, int n, float *C_dev, float *mxp_host)
+{
+    if (!e || !mxp_host) return e ? fail(e, CUSK_ERR_ARG, "bad arguments") : CUSK_ERR_ARG;
+    int rc = corr_build_batch_impl(e, 1, bed_dev, phen_dev, mean_dev, std_dev, N, p, nblk, first_marker, markers, base, nullptr, (size_t)n,
+                                   C_dev, mxp_host, true);
+    if (rc != CUSK_OK) return rc;
+    rc = corr_build_batch_impl(e, 2, bed_dev, phen_dev, mean_dev, std_dev, N, p, nblk, first_marker, markers, base, nullptr, (size_t)n, C_dev,
+                               nullptr);
+    if (rc != CUSK_OK) return rc;
+    if (p == 0) return CUSK_OK;
+    CUSK_HIP(e, hipEventSynchronize(e->ev_mxp));
+    size_t cnt = 0;
+    for (int b = 0; b < nblk; b++) cnt += (size_t)markers[b] * p;
+    std::memcpy(mxp_host, e->mxp_pinned, sizeof(float) * cnt);
+    return CUSK_OK;
 }
 
 extern "C" int cusk_corr_build_begin(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, size_t m, size_t N,

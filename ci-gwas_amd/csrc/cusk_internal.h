@@ -72,6 +72,7 @@ struct cusk_engine
     float *mxp_pinned = nullptr;    // pinned landing buffer of the prefetched marker x trait correlations
     size_t mxp_pinned_cap = 0, mxp_pending = 0;  // floats; mxp_pending > 0: a build is in flight on stream3
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_z = nullptr;
+    hipEvent_t ev_mxp = nullptr;  // cusk_corr_build_batch: the marker x trait correlations have landed in mxp_pinned
     bool own_stream = false;
     std::string err;
 

@@ -918,7 +918,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     for (int l = 0; l < kLevels; l++)
         for (hipEvent_t ev : {e->ev_k0[l], e->ev_k1[l], e->ev_l0[l], e->ev_l1[l]})
             if (ev) (void)hipEventDestroy(ev);
-    for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z})
+    for (hipEvent_t ev : {e->ev_fork, e->ev_join, e->ev_z, e->ev_mxp})
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream3) (void)hipStreamDestroy(e->stream3);

@@ -109,10 +109,11 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     scr.C.reserve(n1 * n1);
 
     // ---- correlations: marker x trait first (prefilter, cli.cpp:550-576), the rest for the blocks that pass ----
+    // (the marker x marker part is enqueued for every block at once and runs while the host does the prefilter)
     std::vector<float> mxp(msum * p);
-    if (cusk_corr_build_batch_mxp(e, staged.bed, staged.phen, staged.means, staged.stds, N, p, B, first.data(), m.data(), base.data(),
-                                  (int)n1, scr.C.p, mxp.data()) != CUSK_OK)
-        engine_die("correlation build (marker x trait)", e);
+    if (cusk_corr_build_batch(e, staged.bed, staged.phen, staged.means, staged.stds, N, p, B, first.data(), m.data(), base.data(), (int)n1,
+                              scr.C.p, mxp.data()) != CUSK_OK)
+        engine_die("correlation build", e);
     mark("mxp");
     std::vector<unsigned char> keep((size_t)B, 0);
     std::vector<int> kept;
@@ -138,9 +139,6 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
         bs.ms_corr = ms_since(t);
         return;
     }
-    if (cusk_corr_build_batch_mxm(e, staged.bed, staged.phen, staged.means, staged.stds, N, p, B, first.data(), m.data(), base.data(),
-                                  keep.data(), (int)n1, scr.C.p) != CUSK_OK)
-        engine_die("correlation build (marker x marker)", e);
     mark("mxm_enq");
     bs.ms_corr = ms_since(t);
 

@@ -220,21 +220,23 @@ class _Queue:
 
 
 def run_rank_batched(bs, queue: "_Queue", device: int, batch_vars: int, options: dict | None = None, write_dir: str | None = None,
-                     engine_factory=None):
+                     engine_factory=None, inflight: int = 1):
     """The rank's blocks in batches of at most `batch_vars` padded variables, each batch through cusk_blockset_run_batch
     (one level loop per stage for the whole batch).  -> (list of BatchResult, list of CuskBatchStats).  write_dir: the
     files of a batch are written (by the library, cusk_batch_result_write) on a thread of their own beside the next batch."""
+    inflight = max(1, int(inflight))
     if engine_factory is not None:  # CPU tests of the batching / gather logic with a stand-in block set
-        eng = engine_factory()
+        engines = [engine_factory() for _ in range(inflight)]
     else:
         cache = bs._engines.setdefault(device, [])
-        if not cache:
+        while len(cache) < inflight:
             cache.append(Engine(device))
-        eng = cache[0]
-    for k, v in (options or {}).items():
-        if k != "corr_ahead":
-            eng.set_option(k, int(v))
-    if engine_factory is None and not bs.stage(eng):
+        engines = cache[:inflight]
+    for eng in engines:
+        for k, v in (options or {}).items():
+            if k != "corr_ahead":
+                eng.set_option(k, int(v))
+    if engine_factory is None and not bs.stage(engines[0]):
         raise RuntimeError("batched runs need the block set's inputs on the device (cusk_blockset_stage failed)")
     def batches():
         """batches drawn from the queue as they are needed (with the shared counter of the dynamic schedule a rank must not
@@ -275,15 +277,36 @@ def run_rank_batched(bs, queue: "_Queue", device: int, batch_vars: int, options:
     wt = threading.Thread(target=writer) if wq is not None else None
     if wt is not None:
         wt.start()
+    # `inflight` batches at a time, one host thread and one engine each: the host part of a batch (tables, prefilter,
+    # pruning, reduction: about half of its wall clock) runs beside the device part of another
+    gen = batches()
+    glock = threading.Lock()
+
+    def worker(eng):
+        try:
+            while not errors:
+                with glock:
+                    batch = next(gen, None)
+                if batch is None:
+                    return
+                br, st = bs.run_batch(eng, batch)
+                with glock:
+                    results.append(br)
+                    stats.append(st)
+                if wq is not None:
+                    wq.put(br)
+        except Exception as exc:  # noqa: BLE001 -- re-raised on the calling thread
+            errors.append(exc)
+
     try:
-        for batch in batches():
-            if errors:
-                break
-            br, st = bs.run_batch(eng, batch)
-            results.append(br)
-            stats.append(st)
-            if wq is not None:
-                wq.put(br)
+        if inflight == 1:
+            worker(engines[0])
+        else:
+            threads = [threading.Thread(target=worker, args=(e_,)) for e_ in engines]
+            for t_ in threads:
+                t_.start()
+            for t_ in threads:
+                t_.join()
     finally:
         if wt is not None:
             wq.put(None)
@@ -430,7 +453,7 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
         # per-batch stats, and the assignment
         t0 = time.perf_counter()
         bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer == "local" else None,
-                                        engine_factory=engine_factory)
+                                        engine_factory=engine_factory, inflight=inflight)
         done = sorted(b for r in bres for b in r.block_indices)
         t1 = time.perf_counter()
         if writer == "local":

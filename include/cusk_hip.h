@@ -242,6 +242,11 @@ int cusk_corr_build_pending(const cusk_engine *e); /* 1 while a cusk_corr_build_
  *          are there.
  *   _mxm : marker x marker (Kendall-npn on the FP4 matrix pipe), trait x trait and the unit diagonal of the blocks with
  *          keep[b] != 0 (keep = NULL: all); asynchronous on the engine's stream. */
+/* both in one call, _mxm speculatively for EVERY block: returns when the marker x trait correlations are in mxp_host,
+ * with the marker x marker part still running on the engine's stream (the caller's prefilter overlaps it) */
+int cusk_corr_build_batch(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
+                          const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
+                          const int *markers, const int *base, int n, float *C_dev, float *mxp_host);
 int cusk_corr_build_batch_mxp(cusk_engine *e, const unsigned char *bed_dev, const float *phen_dev, const float *mean_dev,
                               const float *std_dev, size_t N, size_t p, int nblk, const long long *first_marker,
                               const int *markers, const int *base, int n, float *C_dev, float *mxp_host);

@@ -10,6 +10,7 @@ nb = int(sys.argv[1]) if len(sys.argv) > 1 else 25
 L1 = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 L2 = int(sys.argv[3]) if len(sys.argv) > 3 else 14
 BV = [int(v) for v in sys.argv[4].split(",")] if len(sys.argv) > 4 else [0, 4096, 8192, 16384, 32768]
+INFL = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 N, p = 16384, 20
 d = tempfile.mkdtemp(prefix="chrom_", dir="/tmp")
 sizes = synth.chromosome_block_sizes(nb)
@@ -29,7 +30,7 @@ for bv in BV:
             out = os.path.join(d, f"out{k}"); os.makedirs(out); k += 1
             tm = {}
             t0 = time.perf_counter()
-            done, stats, owned = rb.run_job(bs, out, 0, writer=writer, batch_vars=bv, options={"timing": 0}, timings=tm)
+            done, stats, owned = rb.run_job(bs, out, 0, writer=writer, batch_vars=bv, options={"timing": 0}, timings=tm, inflight=INFL)
             dt = time.perf_counter() - t0
         if bv:
             ph = {q: sum(getattr(s, q) for s in stats) for q in ("ms_corr", "ms_stage1", "ms_prune", "ms_stage2", "ms_reduce")}
