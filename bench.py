@@ -515,11 +515,15 @@ def main():
             main_ms[l] = main_detail[l]
     # dominant kernel = the level whose sweep kernel takes the most device time; its duration comes from HIP
     # events the engine records on its own stream around that kernel alone (cusk_stats.main_kernel_ms)
-    traffic = None
+    # HBM-side bytes per launch from the committed PMC passes (profiles/pmc_traffic.json: the headline block's cusk
+    # engine; FETCH_SIZE corrected as the guide prescribes for gfx950, x 2 -- the run's own calibration beside it)
+    traffic, traffic_detail = None, None
     tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tf):
+    if os.path.exists(tf) and args.engine == "cusk":
         try:
-            traffic = json.load(open(tf)).get(f"level{lv}")
+            tj = json.load(open(tf))
+            traffic = tj.get(f"level{lv}")
+            traffic_detail = {k: v for k, v in tj.items() if k != "note" and (k.startswith(f"level{lv}") or k in ("fetch_calibration", "kernel"))}
         except Exception:  # noqa: BLE001
             traffic = None
     headline = (m == 10000 and p == 20 and N == 16384 and args.max_level == 5 and args.engine == "cusk")
@@ -579,6 +583,8 @@ def main():
                           "total_incl_h2d": corr_ms[3]},
         "synth_gen_s": t_gen,
     }
+    if traffic_detail:
+        out["roofline"]["traffic_detail"] = traffic_detail
     if args.engine == "cusk" and sum(st.canonical_tests) > 0:
         # `value` = canonical CI tests (the sequential schedule of the reference algorithm, computed on the device from
         # the selected ranks and checked against the oracle's own count below) over the measured time
@@ -591,6 +597,8 @@ def main():
         # inflated by doing needless work; roofline_executed = the same with the launch's own test counter
         ex_r = out["roofline"]
         out["roofline"] = roofline_of(lv, int(st.canonical_tests[lv]), int(st.subsets[lv]), n, main_ms[lv], args.engine, traffic)
+        if traffic_detail:
+            out["roofline"]["traffic_detail"] = traffic_detail
         out["roofline_counts"] = ("tests of the dominant kernel's level in the CANONICAL (sequential) schedule (device counter, equal to "
                                   "the oracle's count: parity.canonical_count_equal)")
         # NOT a roofline (the operands of the extra tests come from LDS, not HBM): how many tests the launch executed per second

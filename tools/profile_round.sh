@@ -5,6 +5,16 @@ python3 -c "import torch" > /dev/null 2>&1
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1 && grep '^{' $O/bench.log > $O/${TAG}_bench.json
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/trace.log 2>&1)
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats.csv
+# the hetcor engine on the same block (bench.py --engine cuskss): bench line + kernel stats
+timeout -k 10 600 python3 bench.py --engine cuskss --steps 20 --warmup 3 --no-chromosome > $O/bench_cuskss.log 2>&1 && grep '^{' $O/bench_cuskss.log > $O/${TAG}_bench_cuskss.json
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ss -o t -- python3 $R/bench.py --engine cuskss --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/trace_ss.log 2>&1)
+cp $(find $O/trace_ss -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_cuskss_kernel_stats.csv
+# whole-chromosome job (the `scale` leg): kernel stats of the batched block driver alone
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_chrom -o t -- python3 $R/bench.py --workload chromosome --steps 5 --warmup 1 > $O/trace_chrom.log 2>&1)
+cp $(find $O/trace_chrom -name '*kernel_stats.csv' | head -1) $O/${TAG}_chromosome_kernel_stats.csv
+grep '^{' $O/trace_chrom.log > $O/${TAG}_chromosome_bench.json
+# kernel timeline of one headline step
+(cd /tmp && export TMPDIR=/tmp && timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof -o r -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/p.log 2>&1); python3 tools/timeline.py $O/prof/r_results.db > $O/${TAG}_timeline.txt
 # the sepselect path: kernel stats of one timing run, JSON line of the tool beside it
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ss -o s -- python3 $R/tests/perf_sepselect.py --traits 80 --markers 8000 --sample-pairs 20 > $O/ss.log 2>&1)
 cp $(find $O/ss -name '*kernel_stats.csv' | head -1) $O/${TAG}_sepselect_kernel_stats.csv
@@ -35,19 +45,21 @@ def per_launch(kpat):
     f = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "FETCH_SIZE"]
     w = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "WRITE_SIZE"]
     return (f[0] if f else 0.0) * 1024, (w[0] if w else 0.0) * 1024
-f1, w1 = per_launch("level1_rows")
+K1 = "level1_rows2_kernel<0, false, 512, true>"
+f1, w1 = per_launch(K1)
 # calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"): the level-0 kernel
 # streams the upper triangle of the 10020^2 fp32 matrix once with the same 4-byte-per-lane coalesced loads
 f0, _ = per_launch("level0_wide_kernel")
 n0 = 10020
 known0 = 4.0 * n0 * (n0 - 1) / 2
 cal = known0 / f0 if f0 > 0 else 1.0
-json.dump({"level1": f1 * cal + w1, "level1_fetch_reported": f1, "level1_write": w1, "fetch_calibration": cal,
-           "level0_fetch_reported": f0, "level0_known_bytes": known0,
-           "note": "HBM-side bytes per launch of level1_rows_kernel<0,false>: FETCH_SIZE x 1024 x calibration + WRITE_SIZE x 1024, "
-                   "separate PMC passes (" + TAG + "). Calibration: level0_wide_kernel reads a known " + str(int(known0)) +
-                   " bytes (upper triangle, 4-byte-per-lane coalesced loads, the same access width as the level-1 streams) and "
-                   "FETCH_SIZE reports 1/calibration of them (gfx950 tallies 128-byte requests at 64 bytes)"},
+json.dump({"level1": f1 * 2.0 + w1, "level1_guide_x2": f1 * 2.0 + w1, "level1_calibrated": f1 * cal + w1,
+           "level1_fetch_reported": f1, "level1_write": w1, "fetch_calibration": cal,
+           "level0_fetch_reported": f0, "level0_known_bytes": known0, "kernel": K1,
+           "note": "HBM-side bytes per launch of " + K1 + ", separate PMC passes (" + TAG + "): FETCH_SIZE x 1024 x correction + WRITE_SIZE x 1024. "
+                   "`level1` (what bench.py prints as roofline.traffic) uses the guide's gfx950 correction, FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM: "
+                   "128-byte requests tallied at 64 bytes); `level1_calibrated` uses this run's own calibration instead: level0_wide_kernel reads a known " +
+                   str(int(known0)) + " bytes (upper triangle, 4-byte-per-lane coalesced loads) and FETCH_SIZE reports 1/fetch_calibration of them"},
           open(f"{O}/pmc_traffic.json", "w"), indent=1)
 PY
 ls $O | head -30
