@@ -106,6 +106,7 @@ SYMBOLS = {
     "cusk_result_pmax": (_i, [_vp, _vp, _vp]),
     "cusk_result_sepset_dense": (_i, [_vp, _vp]),
     "cusk_result_sepsets": (_ll, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cusk_result_sepsets_view": (_ll, [_vp, _vp, _vp, _vp]),
     "cusk_corr_build": (_i, [_vp, _vp, _vp, _sz, _sz, _sz, _vp, _vp, _vp, _vp]),
     "cusk_corr_build_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp, _i, _vp, _vp]),
     "cusk_corr_build_batch_mxp": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _sz, _i, _vp, _vp, _vp, _i, _vp, _vp]),

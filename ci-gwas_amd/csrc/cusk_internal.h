@@ -105,6 +105,8 @@ struct cusk_engine
     cusk::DevBuf row_range, row_blk, blk_woff;
     void *batch_pinned = nullptr;  // staging of the per-row tables
     size_t batch_pinned_cap = 0;
+    void *res_pinned = nullptr;    // cusk_result_sepsets_view: x, y, S of the records
+    size_t res_pinned_cap = 0;
     cusk::DevBuf rv, rpos, sel, wpre;  // level 1, row-streaming kernel: C[X, adj(X)] and {Y, reverse position, off, deg} per CSR slot
     long long nrec = 0;
     // pinned host mirrors

@@ -892,6 +892,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     if (e->stream2) (void)hipStreamSynchronize(e->stream2);
     if (e->stream3) (void)hipStreamSynchronize(e->stream3);
     for (DevBuf *b : {&e->row_range, &e->row_blk, &e->blk_woff, &e->pxp_dev, &e->corr_tab[0], &e->corr_tab[1]}) b->release();
+    if (e->res_pinned) (void)hipHostFree(e->res_pinned);
     for (void *ph : e->corr_tab_pinned)
         if (ph) (void)hipHostFree(ph);
     if (e->batch_pinned) (void)hipHostFree(e->batch_pinned);
@@ -1375,6 +1376,44 @@ extern "C" long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *le
         if (z && fetch(e, z, e->den_z.p, sizeof(float) * c) != hipSuccess) return -1;
         if (S && records_to_host(e, S) != CUSK_OK) return -1;
     }
+    return c;
+}
+
+// x, y and the members of every record in ENGINE-OWNED PINNED host memory: one expand kernel, three copies, one
+// synchronisation (cusk_result_sepsets copies into the caller's pageable arrays, each copy staged and synchronised by the
+// runtime); valid until the next run or result call on this engine
+extern "C" long long cusk_result_sepsets_view(cusk_engine *e, const int **x, const int **y, const int **S)
+{
+    if (!e || !e->have_result || e->mode != 0 || !x || !y || !S) return -1;
+    if (hipSetDevice(e->device) != hipSuccess) return -1;
+    if (materialize_records(e, false) != CUSK_OK) return -1;
+    const long long c = e->nrec;
+    *x = *y = *S = nullptr;
+    if (c <= 0) return c;
+    const size_t bx = sizeof(int) * (size_t)c, bs = sizeof(int) * kML * (size_t)c, need = 2 * bx + bs;
+    if (need > e->res_pinned_cap)
+    {
+        if (e->res_pinned) (void)hipHostFree(e->res_pinned);
+        e->res_pinned = nullptr;
+        e->res_pinned_cap = 0;
+        if (hipHostMalloc(&e->res_pinned, need + need / 2) != hipSuccess) return -1;
+        e->res_pinned_cap = need + need / 2;
+    }
+    if (e->scratch_a.ensure(bs) != hipSuccess) return -1;
+    int *hx = static_cast<int *>(e->res_pinned), *hy = hx + c, *hs = hy + c;
+    hipError_t st = launch_expand_records(e->den_s.as<int>(), e->den_l.as<int>(), e->den_stride, c, e->scratch_a.as<int>(), e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(hx, e->den_x.p, bx, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(hy, e->den_y.p, bx, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipMemcpyAsync(hs, e->scratch_a.p, bs, hipMemcpyDeviceToHost, e->stream);
+    if (st == hipSuccess) st = hipStreamSynchronize(e->stream);
+    if (st != hipSuccess)
+    {
+        (void)fail(e, CUSK_ERR_HIP, hipGetErrorString(st));
+        return -1;
+    }
+    *x = hx;
+    *y = hy;
+    *S = hs;
     return c;
 }
 

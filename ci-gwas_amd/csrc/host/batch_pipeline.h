@@ -306,12 +306,11 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
             Reduced &out = outs[(size_t)kept[(size_t)k]].r;
             out.S.assign(out.num_var * out.num_var * (size_t)ML, -1);
         }
-        const long long cnt = cusk_result_sepsets(e, nullptr, nullptr, nullptr, nullptr, nullptr);
+        const int *x = nullptr, *y = nullptr, *rs = nullptr;  // engine-owned pinned memory
+        const long long cnt = cusk_result_sepsets_view(e, &x, &y, &rs);
         if (cnt < 0) engine_die("sepsets (batch)", e);
         if (cnt > 0)
         {
-            std::vector<int> x((size_t)cnt), y((size_t)cnt), rs((size_t)cnt * ML);
-            if (cusk_result_sepsets(e, x.data(), y.data(), nullptr, nullptr, rs.data()) != cnt) engine_die("sepsets (batch)", e);
             int k = 0;
             std::vector<int> pos, o2n;
             int cur = -1;

@@ -183,11 +183,10 @@ inline std::vector<int> reduce_sepsets(cusk_engine *e, const std::vector<int> &P
 {
     const size_t k = P.size();
     std::vector<int> S(k * k * max_level, -1);
-    const long long cnt = cusk_result_sepsets(e, nullptr, nullptr, nullptr, nullptr, nullptr);
+    const int *x = nullptr, *y = nullptr, *rs = nullptr;  // engine-owned pinned memory
+    const long long cnt = cusk_result_sepsets_view(e, &x, &y, &rs);
     if (cnt < 0) engine_die("sepsets", e);
     if (cnt == 0) return S;
-    std::vector<int> x(cnt), y(cnt), rs((size_t)cnt * ML);
-    if (cusk_result_sepsets(e, x.data(), y.data(), nullptr, nullptr, rs.data()) != cnt) engine_die("sepsets", e);
     std::unordered_map<int, int> pos, old_to_new;
     for (size_t i = 0; i < k; i++)
     {

@@ -215,6 +215,9 @@ int cusk_result_sepset_dense(cusk_engine *e, int *SepSet_host /* n*n*14 */);
  * level: count ints; z: count floats; S: count*14 ints (-1 padded).  The winners' Fisher z is computed on the first
  * request that asks for it (z != NULL, or cusk_result_pmax) from the matrix of the run, which must still be resident. */
 long long cusk_result_sepsets(cusk_engine *e, int *x, int *y, int *level, float *z, int *S);
+/* the same records (x, y, S[count * 14]) in engine-owned PINNED host memory -- one synchronisation, no staging through
+ * pageable memory; the pointers stay valid until the next run or result call on this engine.  Returns the count. */
+long long cusk_result_sepsets_view(cusk_engine *e, const int **x, const int **y, const int **S);
 
 /* Correlation build on the device (a2-a5).  bed/phen/mean/std
  * are HOST buffers as in cu_corr_pearson_npn; the n*n (n = m + p) square
