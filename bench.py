@@ -14,11 +14,12 @@ N > 1 (torchrun, one rank per GPU): BASELINE.json config 4, the whole-chromosome
 (200 blocks x ~500 SNPs x 20 traits on 8 GPUs; weak scaling), written as a PLINK file set, every block through the
 product's block driver (ci-gwas_amd/run_blocks.py: `cusk_blockset_*`, longest-processing-time assignment; the blocks of
 a rank run in batches -- `cusk_blockset_run_batch`: correlation build, stage one, prune, stage two and reduction of all
-blocks of a batch in one set of device runs; .bed staged in HBM once per GPU), no collective in the data path.  Files: by
-default the per-block results are gathered to rank 0 over RCCL -- the one exchange north_star names -- which writes every
-file (--writer rank0; the gather and the writing are timed separately); --writer local lets every rank write the files
-of its own blocks (what the reference's one-process-per-block runs do; only a barrier ends the pass); the line reports
-both.  One step = one pass of the job over the whole chromosome.
+blocks of a batch in one set of device runs; .bed staged in HBM once per GPU), no collective in the data path.  Files
+(--writer merge, the default): every rank writes the files of its own blocks, and the merged skeleton -- what
+`merge-block-outputs` reads of every block -- is gathered to rank 0 over RCCL (the one exchange north_star names), which
+writes merged_blocks* from memory; the gather and rank 0's writing are timed separately.  --writer rank0 gathers the full
+results and lets rank 0 write every file; --writer local has no exchange (what the reference's one-process-per-block runs
+do).  Every line reports all three.  One step = one pass of the job over the whole chromosome.
 
 EVERY line (N = 1 included) carries the same `scale` object -- the whole-chromosome job on this many GPUs, 25 blocks per
 GPU -- and `scale.blocks_per_sec` is the key a scaling curve is to be built from (at N = 1 `value` is the headline block,
@@ -198,14 +199,16 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
 
     def one_pass(writer, timing=0, tm=None):
         out = None
-        if rank == 0 or writer == "local":
+        if rank == 0 or writer in ("local", "merge"):
             counter[0] += 1
             out = os.path.join(workdir, f"out{counter[0]}")
             os.makedirs(out, exist_ok=True)
         # timed passes run without per-level HIP events (a few microseconds of device time each); the per-level kernel
         # times of the roofline come from one untimed detail pass
+        if writer == "merge" and bv <= 0:
+            writer = "rank0"  # (the merge writer is part of the batched path)
         return rb.run_job(bs, out, device, inflight=args.inflight, schedule=args.schedule, collective_device=cdev,
-                          options={"timing": timing}, writer=writer, batch_vars=bv, timings=tm)
+                          options={"timing": timing}, writer=writer, batch_vars=bv, timings=tm, blockfile=blocks)
 
     def totals(stats):
         """(executed tests, canonical tests, phase sums) of one pass's stats (batched: list of batch stats; else per block)"""
@@ -253,7 +256,7 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             dt, ex, ca = float(tmax[0].item()), float(t[1].item()), float(t[2].item())
         nwritten = len(done) if done is not None else 0
-        if writer == "local" and dist is not None:
+        if writer in ("local", "merge") and dist is not None:
             t = torch.tensor([float(nwritten)], dtype=torch.float64, device=cdev if cdev is not None else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             nwritten = int(t[0].item())
@@ -262,8 +265,13 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     one_pass(args.writer)  # first pass of the process: allocations, staging of the .bed
     _, detail_stats, _ = one_pass("local", timing=1)
     dt, ex, ca, ph, tms, nwritten = timed(args.writer, steps, warmup)
-    other = "local" if args.writer == "rank0" else "rank0"
-    dt2, _ex2, _ca2, _ph2, tms2, _nw2 = timed(other, steps, 1)
+    others = {}
+    for other in ("merge", "rank0", "local"):
+        if other == args.writer or (other == "merge" and bv <= 0):
+            continue
+        dt2, _ex2, _ca2, _ph2, tms2, _nw2 = timed(other, steps, 1)
+        others[other] = {"blocks_per_sec": len(sizes) * steps / dt2, "ms_per_pass": dt2 / steps * 1e3,
+                         "gather_ms": tms2.get("gather_s", 0.0) if other != "local" else 0.0, "write_ms": tms2.get("write_s")}
     # per-level totals over this rank's blocks (detail pass): which kernel dominates the device time
     lv_ms, lv_tests, lv_sub, nvar = np.zeros(15), np.zeros(15), np.zeros(15), 0
     for s_ in (detail_stats if bv > 0 else detail_stats.values()):
@@ -283,18 +291,20 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
         "n_gpus": world, "blocks": nb, "blocks_per_gpu": args.blocks_per_gpu, "passes": steps,
         "writer": args.writer,
         "blocks_per_sec": nb * steps / dt, "ms_per_pass": dt / steps * 1e3, "blocks_written_per_pass": nwritten,
-        "gather_ms": tms.get("gather_s", 0.0) if args.writer == "rank0" else 0.0,
+        "gather_ms": tms.get("gather_s", 0.0) if args.writer != "local" else 0.0,
         "write_ms": tms.get("write_s"), "compute_ms": tms.get("compute_s"),
         "rank0_phase_ms_per_pass": ph,
         "ci_tests_per_sec": ca / dt, "ci_tests_per_pass": ca / steps, "executed_ci_tests_per_sec": ex / dt,
-        "other_writer": {"writer": other, "blocks_per_sec": nb * steps / dt2, "ms_per_pass": dt2 / steps * 1e3,
-                         "gather_ms": tms2.get("gather_s", 0.0) if other == "rank0" else 0.0},
+        "other_writers": others,
         "execution": (f"batched: blocks of a rank in batches of <= {bv} padded variables, one correlation build / level loop per stage / read-out "
                       f"per batch (cusk_blockset_run_batch)") if bv > 0 else "one block per engine run (cusk_blockset_run_block)",
         "batch_vars": bv, "schedule": args.schedule,
-        "gather": ("per-block reduced results of every rank -> rank 0: size all_gather + one padded all_gather over "
+        "gather": ("writer merge: every rank writes the files of its own blocks; indices, adjacency and correlations of every block "
+                   "(no separating sets) -> rank 0, which writes the merged skeleton merged_blocks* from memory (cusk_merge_packed = "
+                   "merge-block-outputs).  writer rank0: the full results -> rank 0, which writes every file.  Transport: size all-gather + "
+                   "one gather over "
                    + ("RCCL (backend nccl)" if cdev is not None else ("gloo" if dist is not None else "nothing (one rank)"))
-                   + "; rank 0 writes every file (gather_ms, write_ms: rank 0's wall clock per pass)"),
+                   + "; gather_ms / write_ms: rank 0's wall clock per pass for the exchange / for what it writes after it"),
         "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); result files written inside the timed region",
         "curve_key": "scale.blocks_per_sec (same workload definition at every N: 25 blocks per GPU, weak scaling)",
         "generate_s": t_gen,
@@ -368,10 +378,11 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=25, help="chromosome workload: LD blocks per GPU (config C4: 200 on 8 GPUs)")
     ap.add_argument("--inflight", type=int, default=1, help="chromosome workload: blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
-    ap.add_argument("--writer", choices=["local", "rank0"], default="rank0",
-                    help="chromosome workload: rank0 = one gather of all results (RCCL), rank 0 writes every file; local = every rank "
-                         "writes the files of its own blocks (no exchange, as the reference's one process per block).  Both are measured, "
-                         "this one is the line's blocks_per_sec")
+    ap.add_argument("--writer", choices=["merge", "local", "rank0"], default="merge",
+                    help="chromosome workload: merge = every rank writes the files of its own blocks and the merged skeleton is gathered to "
+                         "rank 0 over RCCL and written there (merged_blocks*: north_star's gather of the merged adjacency); rank0 = one gather "
+                         "of the full results, rank 0 writes every file; local = every rank writes its own blocks' files, no exchange.  All "
+                         "three are measured, this one is the line's blocks_per_sec")
     ap.add_argument("--batch-vars", type=int, default=16384,
                     help="chromosome workload: blocks run in batches of at most this many padded variables (0: one block per engine run)")
     ap.add_argument("--scale-steps", type=int, default=5, help="N = 1: timed passes of the whole-chromosome leg (the `scale` object)")

@@ -139,6 +139,9 @@ SYMBOLS = {
     "cusk_batch_result_packed_bytes": (_sz, [_vp]),
     "cusk_batch_result_pack": (_i, [_vp, _vp, _sz]),
     "cusk_packed_results_write": (_i, [_vp, _sz, C.c_char_p, _vp]),
+    "cusk_batch_result_packed_bytes_ex": (_sz, [_vp, _i]),
+    "cusk_batch_result_pack_ex": (_i, [_vp, _vp, _sz, _i]),
+    "cusk_merge_packed": (_i, [C.c_char_p, _vp, _sz, C.c_char_p]),
     "cusk_batch_result_free": (None, [_vp]),
     "cusk_corr_build_pending": (_i, [_vp]),
     "cusk_block_result_dims": (None, [_vp, C.POINTER(_ll), C.POINTER(_ll), C.POINTER(_ll)]),

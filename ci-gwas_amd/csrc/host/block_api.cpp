@@ -5,6 +5,7 @@
 #include <thread>
 
 #include "batch_pipeline.h"
+#include "merge.h"
 
 using namespace host;
 
@@ -333,29 +334,33 @@ extern "C" int cusk_batch_result_write(const cusk_batch_result *r, const char *o
     return CUSK_OK;
 }
 
-static size_t packed_bytes_of(const cusk_block_result &b)
+static size_t packed_bytes_of(const cusk_block_result &b, bool with_sep)
 {
     const size_t k = b.r.num_var;
-    return 24 + b.stem.size() + 4 * (k + 2 * k * k + k * k * b.r.max_level);
+    return 24 + b.stem.size() + 4 * (k + 2 * k * k + (with_sep ? k * k * b.r.max_level : 0));
 }
 
-extern "C" size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r)
+extern "C" size_t cusk_batch_result_packed_bytes_ex(const cusk_batch_result *r, int with_sep)
 {
     size_t t = 0;
     if (r)
-        for (const cusk_block_result &b : r->blocks) t += packed_bytes_of(b);
+        for (const cusk_block_result &b : r->blocks) t += packed_bytes_of(b, with_sep != 0);
     return t;
 }
+extern "C" size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r) { return cusk_batch_result_packed_bytes_ex(r, 1); }
 
-extern "C" int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes)
+extern "C" int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, size_t bytes, int with_sep);
+extern "C" int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes) { return cusk_batch_result_pack_ex(r, buf, bytes, 1); }
+
+extern "C" int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, size_t bytes, int with_sep)
 {
     if (!r || (!buf && bytes)) return CUSK_ERR_ARG;
-    if (bytes < cusk_batch_result_packed_bytes(r)) return CUSK_ERR_ARG;
+    if (bytes < cusk_batch_result_packed_bytes_ex(r, with_sep)) return CUSK_ERR_ARG;
     char *p = static_cast<char *>(buf);
     for (size_t i = 0; i < r->blocks.size(); i++)
     {
         const cusk_block_result &b = r->blocks[i];
-        const int head[6] = {r->index[i], (int)b.r.num_var, (int)b.r.num_phen, (int)b.r.max_level, 1, (int)b.stem.size()};
+        const int head[6] = {r->index[i], (int)b.r.num_var, (int)b.r.num_phen, (int)b.r.max_level, with_sep ? 1 : 0, (int)b.stem.size()};
         std::memcpy(p, head, 24);
         p += 24;
         std::memcpy(p, b.stem.data(), b.stem.size());
@@ -367,7 +372,66 @@ extern "C" int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, siz
         put(b.r.new_to_old.data(), 4 * b.r.new_to_old.size());
         put(b.r.G.data(), 4 * b.r.G.size());
         put(b.r.C.data(), 4 * b.r.C.size());
-        put(b.r.S.data(), 4 * b.r.S.size());
+        if (with_sep) put(b.r.S.data(), 4 * b.r.S.size());
+    }
+    return CUSK_OK;
+}
+
+// `merge-block-outputs` (merge_blocks.py:361-395) on the packed results of a whole job: the merged sparse skeleton files
+// <basepath>_sam.mtx, _scm.mtx, .mdim, .ixs, without reading the per-block files back (host/merge.h)
+extern "C" int cusk_merge_packed(const char *blockfile, const void *buf, size_t bytes, const char *basepath)
+{
+    if (!blockfile || (!buf && bytes) || !basepath) return CUSK_ERR_ARG;
+    try
+    {
+        const std::vector<Block> listed = read_blocks(blockfile);
+        std::map<std::string, size_t> where;  // stem -> line of the .blocks file
+        for (size_t i = 0; i < listed.size(); i++) where[listed[i].file_stem()] = i;
+        std::vector<MergeInput> in(listed.size());
+        std::vector<size_t> sizes(listed.size());
+        for (size_t i = 0; i < listed.size(); i++) sizes[i] = listed[i].size();
+        // (int / float arrays inside the byte string are 4-byte aligned only if the stems' lengths allow: copy them out)
+        std::vector<std::vector<int>> ixs(listed.size()), adj(listed.size());
+        std::vector<std::vector<float>> corr(listed.size());
+        const char *p = static_cast<const char *>(buf), *end = p + bytes;
+        while (p < end)
+        {
+            if (end - p < 24) throw std::runtime_error("truncated packed results");
+            int head[6];
+            std::memcpy(head, p, 24);
+            p += 24;
+            const size_t k = (size_t)head[1], ml = (size_t)head[3], ns = (size_t)head[5];
+            const bool has_sep = head[4] != 0;
+            if ((size_t)(end - p) < ns + 4 * (k + 2 * k * k + (has_sep ? k * k * ml : 0))) throw std::runtime_error("truncated packed results");
+            const std::string stem(p, ns);
+            p += ns;
+            auto it = where.find(stem);
+            if (it == where.end()) throw std::runtime_error("result of a block that is not in the block file: " + stem);
+            const size_t at = it->second;
+            ixs[at].resize(k);
+            adj[at].resize(k * k);
+            corr[at].resize(k * k);
+            std::memcpy(ixs[at].data(), p, 4 * k);
+            p += 4 * k;
+            std::memcpy(adj[at].data(), p, 4 * k * k);
+            p += 4 * k * k;
+            std::memcpy(corr[at].data(), p, 4 * k * k);
+            p += 4 * k * k;
+            if (has_sep) p += 4 * k * k * ml;
+            in[at].present = true;
+            in[at].num_var = k;
+            in[at].num_phen = (size_t)head[2];
+            in[at].max_level = ml;
+            in[at].ixs = ixs[at].data();
+            in[at].adj = adj[at].data();
+            in[at].corr = corr[at].data();
+        }
+        merge_blocks_to_files(in, sizes, basepath);
+    }
+    catch (const std::exception &ex)
+    {
+        copy_err(ex.what(), nullptr, 0);
+        return CUSK_ERR_ARG;
     }
     return CUSK_OK;
 }

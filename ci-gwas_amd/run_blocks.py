@@ -140,11 +140,12 @@ class BatchResult:
         if lib().cusk_batch_result_write(self.h, outdir.encode()) != 0:
             raise RuntimeError(f"writing batch results: {lib().cusk_blockset_last_error().decode()}")
 
-    def pack(self) -> np.ndarray:
-        """the results as one byte string (shard.BlockResult.pack layout, block after block)"""
-        nbytes = int(lib().cusk_batch_result_packed_bytes(self.h))
+    def pack(self, with_sep: bool = True) -> np.ndarray:
+        """the results as one byte string (shard.BlockResult.pack layout, block after block); with_sep = False leaves the
+        .sep arrays out (nine tenths of the bytes; the merge does not read them)"""
+        nbytes = int(lib().cusk_batch_result_packed_bytes_ex(self.h, 1 if with_sep else 0))
         buf = np.zeros(nbytes, np.uint8)
-        if nbytes and lib().cusk_batch_result_pack(self.h, buf.ctypes.data_as(C.c_void_p), nbytes) != 0:
+        if nbytes and lib().cusk_batch_result_pack_ex(self.h, buf.ctypes.data_as(C.c_void_p), nbytes, 1 if with_sep else 0) != 0:
             raise RuntimeError("cusk_batch_result_pack failed")
         return buf
 
@@ -174,6 +175,13 @@ def write_packed(buf: np.ndarray, outdir: str) -> int:
     if lib().cusk_packed_results_write(buf.ctypes.data_as(C.c_void_p), buf.size, outdir.encode(), C.byref(n)) != 0:
         raise RuntimeError(f"writing gathered results: {lib().cusk_blockset_last_error().decode()}")
     return int(n.value)
+
+
+def merge_packed(blockfile: str, buf: np.ndarray, basepath: str) -> None:
+    """cusk_merge_packed: `merge-block-outputs` on the gathered results in memory -> <basepath>_sam.mtx, _scm.mtx, .mdim, .ixs"""
+    buf = np.ascontiguousarray(buf, np.uint8)
+    if lib().cusk_merge_packed(blockfile.encode(), buf.ctypes.data_as(C.c_void_p), buf.size, basepath.encode()) != 0:
+        raise RuntimeError(f"merging the gathered results: {lib().cusk_blockset_last_error().decode()}")
 
 
 def make_batches(blocks: list[int], sizes: dict, num_phen: int, batch_vars: int) -> list[list[int]]:
@@ -425,14 +433,19 @@ def run_rank(bs, queue: _Queue, device: int, inflight: int = 1, options: dict | 
 
 def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: str = "lpt", collective_device=None,
             options: dict | None = None, group=None, engine_factory=None, store_key: str = "cusk_next_block",
-            stage: bool = True, writer: str = "rank0", batch_vars: int = 0, timings: dict | None = None):
+            stage: bool = True, writer: str = "rank0", batch_vars: int = 0, timings: dict | None = None, blockfile: str | None = None):
     """One rank's part of the job (call on every rank of an initialised process group, or without one for a
     single-process run).  Returns (all results on rank 0 / None elsewhere, this rank's stats, assignment).
 
     writer = "rank0": the per-block results are gathered to rank 0 (one exchange at the end of the job), which writes
     every file.  writer = "local": every rank writes the files of its own blocks into `outdir` (a directory all ranks
     of the node see) -- what the reference's one-process-per-block runs do; no exchange at all, only a barrier, and the
-    writing is spread over the ranks instead of serialised on one (returns this rank's results)."""
+    writing is spread over the ranks instead of serialised on one (returns this rank's results).  writer = "merge"
+    (batched execution; needs `blockfile`): both -- every rank writes its own blocks' files, and what `merge-block-outputs`
+    reads of them (indices, adjacency, correlations: no separating sets, a tenth of the bytes) is gathered to rank 0,
+    which writes the MERGED skeleton `<outdir>/merged_blocks{_sam.mtx,_scm.mtx,.mdim,.ixs}` straight from memory
+    (cusk_merge_packed): the job ends with the input of `cuskss-merged` / `sepselect` on disk and rank 0 writes four small
+    files instead of five per block."""
     import torch.distributed as dist
 
     distributed = dist.is_available() and dist.is_initialized()
@@ -452,13 +465,29 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
         # that were written (all of the job's on rank 0 with writer = rank0, the rank's own with writer = local), the
         # per-batch stats, and the assignment
         t0 = time.perf_counter()
-        bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer == "local" else None,
+        if writer == "merge" and blockfile is None:
+            raise ValueError("writer = 'merge' needs the job's .blocks file")
+        bres, bstats = run_rank_batched(bs, queue, device, batch_vars, options, write_dir=outdir if writer in ("local", "merge") else None,
                                         engine_factory=engine_factory, inflight=inflight)
         done = sorted(b for r in bres for b in r.block_indices)
         t1 = time.perf_counter()
         if writer == "local":
             if distributed:
                 dist.barrier(group)
+        elif writer == "merge":
+            payload = np.concatenate([r.pack(with_sep=False) for r in bres]) if bres else np.zeros(0, np.uint8)
+            parts = gather_packed(payload, device=collective_device, group=group) if distributed else [payload]
+            t2 = time.perf_counter()
+            if timings is not None:
+                timings["gather_s"] = t2 - t1
+            if rank == 0 and outdir is not None:
+                allp = np.concatenate(parts) if parts else np.zeros(0, np.uint8)
+                if allp.size:
+                    merge_packed(blockfile, allp, os.path.join(outdir, "merged_blocks"))
+            if timings is not None:
+                timings["write_s"] = time.perf_counter() - t2
+            if distributed:
+                dist.barrier(group)  # every rank's own files are on disk when the job returns
         else:
             payload = np.concatenate([r.pack() for r in bres]) if bres else np.zeros(0, np.uint8)
             if distributed:
@@ -518,8 +547,10 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo: CPU collectives)")
     ap.add_argument("--inflight", type=int, default=1, help="blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
-    ap.add_argument("--writer", choices=["rank0", "local"], default="rank0",
-                    help="rank0: results gathered to rank 0, which writes every file; local: every rank writes the files of its own blocks")
+    ap.add_argument("--writer", choices=["merge", "rank0", "local"], default="merge",
+                    help="merge (batched execution): every rank writes the files of its own blocks, the merged skeleton is gathered "
+                         "to rank 0 (RCCL) and written there as merged_blocks*; rank0: full results gathered to rank 0, which writes "
+                         "every file; local: every rank writes its own blocks' files, no exchange")
     ap.add_argument("--batch-vars", type=int, default=16384,
                     help="blocks are run in batches of at most this many (padded) variables, one level loop per stage for the "
                          "whole batch; 0: one block per engine run")
@@ -552,8 +583,9 @@ def main(argv=None):
     # no per-level HIP events: nothing here reads the per-level kernel times, and every event costs the launch-bound
     # small blocks a few microseconds of device time
     batch_vars = 0 if args.no_stage else max(0, args.batch_vars)
+    writer = args.writer if (batch_vars > 0 or args.writer != "merge") else "rank0"  # (merge is part of the batched path)
     allr, stats, owned = run_job(bs, args.outdir, device, args.inflight, args.schedule, cdev, stage=not args.no_stage,
-                                 options={"timing": 0}, writer=args.writer, batch_vars=batch_vars)
+                                 options={"timing": 0}, writer=writer, batch_vars=batch_vars, blockfile=args.blocks)
     dt = time.perf_counter() - t0
     if batch_vars > 0:
         tests = sum(int(s.tests[0]) + int(s.tests[1]) for s in stats)
@@ -563,8 +595,9 @@ def main(argv=None):
         nblk, nskip = len(stats), sum(1 for s in stats.values() if s.skipped)
     print(f"[rank {rank}/{world}] gpu {device}: {nblk} blocks ({nskip} skipped), "
           f"{tests:.3e} CI tests, open {t_open:.2f} s, total {dt:.2f} s", flush=True)
-    if rank == 0 or args.writer == "local":
-        print(f"[rank {rank}] wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}", flush=True)
+    if rank == 0 or writer in ("local", "merge"):
+        print(f"[rank {rank}] wrote {len(allr)} of {bs.num_blocks} blocks to {args.outdir}"
+              + (" + merged_blocks*" if (writer == "merge" and rank == 0) else ""), flush=True)
     bs.close()
     if world > 1:
         dist.barrier()

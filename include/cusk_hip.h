@@ -382,6 +382,14 @@ int cusk_batch_result_write(const cusk_batch_result *r, const char *outdir);   /
 size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r);
 int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes);
 int cusk_packed_results_write(const void *buf, size_t bytes, const char *outdir, int *blocks_written);
+/* the same byte string without the .sep arrays (nine tenths of the bytes; with_sep = 0): what the merge below needs */
+size_t cusk_batch_result_packed_bytes_ex(const cusk_batch_result *r, int with_sep);
+int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, size_t bytes, int with_sep);
+/* `merge-block-outputs` (cusk_postprocessing/merge_blocks.py:361-395 + write_mm :298-325) on the packed results of a whole
+ * job, in memory: writes <basepath>_sam.mtx, <basepath>_scm.mtx, <basepath>.mdim, <basepath>.ixs -- the files the
+ * reference's merge writes from the per-block files, byte for byte.  blockfile = the job's .blocks file (order of the
+ * blocks; a listed block without a result counts as skipped, as a block without files does there). */
+int cusk_merge_packed(const char *blockfile, const void *buf, size_t bytes, const char *basepath);
 void cusk_batch_result_free(cusk_batch_result *r);
 /* the reduced result of one block: what ReducedGCS::to_file writes (include/mps/parent_set.h:42-52) */
 void cusk_block_result_dims(const cusk_block_result *r, long long *num_var, long long *num_phen, long long *max_level);

@@ -255,3 +255,32 @@ def test_depth_two_batch_equals_per_block_and_oracle(chromosome, oracle):
     rb.lib().cusk_blockset_release_engine(bs.h, e.h)
     e.close()
     bs.close()
+
+
+def test_merge_writer_leaves_block_files_and_the_merged_skeleton(chromosome, tmp_path, capsys):
+    """writer = "merge": every block's five files as per-block `mps cusk` writes them, plus the merged skeleton written by
+    the library from the gathered results -- equal to what `merge-block-outputs` makes of those files (this package's
+    mirror, pinned by reference-written goldens, and the oracle's restatement)"""
+    from cigwas_amd import cli
+    from cigwas_amd import run_blocks as rb
+    from oracle import merge_oracle as MO
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), int(DEPTH))
+    out = tmp_path / "out"
+    out.mkdir()
+    done, stats, owned = rb.run_job(bs, str(out), device=0, writer="merge", batch_vars=2048, options={"timing": 0}, blockfile=chromosome["blocks"])
+    bs.close()
+    merged = ["merged_blocks_sam.mtx", "merged_blocks_scm.mtx", "merged_blocks.mdim", "merged_blocks.ixs"]
+    got = {f: open(out / f, "rb").read() for f in merged}
+    for f in merged:
+        os.remove(out / f)
+    _same_files(str(chromosome["ref"]), str(out))
+    cli.main(["merge-block-outputs", str(out), chromosome["blocks"]])
+    assert "Missing:" in capsys.readouterr().out  # blocks without signal have no files
+    for f in merged:
+        assert open(out / f, "rb").read() == got[f], f
+    exp = tmp_path / "mo"
+    exp.mkdir()
+    MO.write_mm(MO.merge(chromosome["blocks"], str(out) + "/"), str(exp / "merged_blocks"))
+    for f in merged:
+        assert open(exp / f, "rb").read() == got[f], f

@@ -74,6 +74,65 @@ def test_merge_oracle_reproduces_the_reference_files(tmp_path):
     _same_dir(os.path.join(G, "cuskss_merged"), str(d), sorted(os.listdir(os.path.join(G, "cuskss_merged"))))
 
 
+def _pack_block_files(blockdir, stems_in_order, with_sep=False):
+    """per-block result files -> the byte string the multi-GPU job gathers (shard.BlockResult.pack layout)"""
+    from cigwas_amd import shard
+
+    parts = []
+    for bi, stem in enumerate(stems_in_order):
+        base = os.path.join(blockdir, stem)
+        if not os.path.exists(base + ".mdim"):
+            continue
+        nv, nph, ml = (int(v) for v in open(base + ".mdim").read().split())
+        r = shard.BlockResult(bi, stem, nph, ml, np.fromfile(base + ".ixs", np.int32), np.fromfile(base + ".adj", np.int32).reshape(nv, nv),
+                              np.fromfile(base + ".corr", np.float32).reshape(nv, nv), None)
+        parts.append(r.pack())
+    return np.concatenate(parts[::-1])  # any order: the merge goes by the block file
+
+
+def test_library_merge_of_packed_results_writes_the_files_the_reference_wrote(tmp_path):
+    """cusk_merge_packed (csrc/host/merge.h: the merged skeleton straight from the gathered results, host code of the library)
+    against the files the REFERENCE's merge_block_outputs wrote from the same per-block files"""
+    import ctypes as C
+
+    from cigwas_amd import merge
+    from cigwas_amd._lib import lib
+
+    blockfile = os.path.join(G, "inputs", "blocks.txt")
+    buf = _pack_block_files(os.path.join(G, "blocks"), merge.block_stems(blockfile))
+    rc = lib().cusk_merge_packed(blockfile.encode(), buf.ctypes.data_as(C.c_void_p), buf.size, str(tmp_path / "merged_blocks").encode())
+    assert rc == 0, lib().cusk_blockset_last_error()
+    _same_dir(os.path.join(G, "merged"), str(tmp_path))
+
+
+def test_library_prints_floats_as_numpy_does():
+    """the .mtx values are f"{numpy.float32}" = repr(float(v)): shortest digits of the double, positional for exponents in [-4, 16)"""
+    import ctypes as C
+
+    from cigwas_amd import merge, shard
+    from cigwas_amd._lib import lib
+    import tempfile
+
+    rng = np.random.default_rng(1)
+    vals = np.concatenate([rng.uniform(-1, 1, 300), 10.0 ** rng.uniform(-9, -3, 200) * rng.choice([-1, 1], 200),
+                           [1.0, -1.0, 0.1, 1e-4, 9.9999e-5, 0.00012345, 1e-5, 0.5, 1e-45, 3.4028235e38, 123456.0, 1e15, 1e16, np.nan]])
+    vals = vals.astype(np.float32)
+    k = len(vals)
+    corr = np.zeros((k + 1, k + 1), np.float32)
+    corr[0, 1:] = vals  # one row of non-zeros: entries (k + 1? no: marker 0 -> merged index p + 1 = 2; trait -> 1)
+    adj = np.zeros((k + 1, k + 1), np.int32)
+    adj[0, 1] = 1
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "b.blocks"), "w").write(f"1\t0\t{k - 1}\n")
+        r = shard.BlockResult(0, f"1_0_{k - 1}", 1, 14, np.arange(k + 1, dtype=np.int32), adj, corr, None)
+        buf = r.pack()
+        rc = lib().cusk_merge_packed(os.path.join(d, "b.blocks").encode(), buf.ctypes.data_as(C.c_void_p), buf.size, os.path.join(d, "m").encode())
+        assert rc == 0
+        got = [ln.split("\t")[2] for ln in open(os.path.join(d, "m_scm.mtx")).read().splitlines()[2:]]
+    want = [f"{v}" for v in vals if v != 0]
+    assert got == want
+
+
 def test_cli_shim_builds_the_argv_of_the_reference_cli():
     """argv lists captured from the reference's ci-gwas.py handlers (subprocess.run intercepted)"""
     from cigwas_amd import cli

@@ -63,8 +63,15 @@ class _OracleBatch:
         self._r = results
         self.block_indices = [r.block_index for r in results]
 
-    def pack(self):
-        return np.concatenate([r.pack() for r in self._r]) if self._r else np.zeros(0, np.uint8)
+    def pack(self, with_sep=True):
+        import copy
+
+        rs = self._r
+        if not with_sep:
+            rs = [copy.copy(r) for r in rs]
+            for r in rs:
+                r.sep = None
+        return np.concatenate([r.pack() for r in rs]) if rs else np.zeros(0, np.uint8)
 
     def write(self, outdir):
         for r in self._r:
@@ -98,8 +105,9 @@ def _batch_worker(rank, world, port, outdir, mode, q):
 
     schedule, writer, bv = mode.split("+")
     tm = {}
+    blockfile = os.path.join(outdir, "..", "b.blocks")
     done, stats, owned = rb.run_job(_OracleBatchSet(), outdir, device=0, schedule=schedule, engine_factory=_NoEngine,
-                                    store_key=f"nextb_{mode}", writer=writer, batch_vars=int(bv), timings=tm)
+                                    store_key=f"nextb_{mode}", writer=writer, batch_vars=int(bv), timings=tm, blockfile=blockfile)
     if writer == "rank0":
         assert (done is None) == (rank != 0) and "gather_s" in tm
         if rank == 0:
@@ -110,7 +118,7 @@ def _batch_worker(rank, world, port, outdir, mode, q):
 
 
 @pytest.mark.timeout(300)
-@pytest.mark.parametrize("mode", ["lpt+rank0+300", "dynamic+rank0+200", "lpt+local+100000"])
+@pytest.mark.parametrize("mode", ["lpt+rank0+300", "dynamic+rank0+200", "lpt+local+100000", "lpt+merge+250"])
 def test_two_rank_batched_job_gathers_packed_results(tmp_path, oracle, synth, mode):
     """the batched job path (run_blocks.run_job with batch_vars > 0) over gloo: batches cut from the rank's queue, ONE gather
     of the packed results to rank 0, files written by the library's packed writer (host code of libcusk_hip.so)"""
@@ -118,6 +126,8 @@ def test_two_rank_batched_job_gathers_packed_results(tmp_path, oracle, synth, mo
 
     out = tmp_path / "o"
     out.mkdir()
+    with open(tmp_path / "b.blocks", "w") as f:  # the stand-in blocks are called 1_<b>_<b>
+        f.write("".join(f"1\t{b}\t{b}\n" for b in range(NBLOCKS)))
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     mp.spawn(_batch_worker, args=(2, _free_port(), str(out), mode, q), nprocs=2, join=True)
@@ -127,6 +137,15 @@ def test_two_rank_batched_job_gathers_packed_results(tmp_path, oracle, synth, mo
         assert all(g[2] <= 1 for g in got)  # one batch per rank
     else:
         assert sum(g[2] for g in got) >= 3
+    if mode.split("+")[1] == "merge":
+        # the merged skeleton rank 0 wrote from the gathered results = the merge of the per-block files (oracle restatement,
+        # pinned by the files the reference wrote)
+        from oracle import merge_oracle as MO
+
+        MO.write_mm(MO.merge(str(tmp_path / "b.blocks"), str(out) + "/"), str(tmp_path / "exp"))
+        for sfx in ("_sam.mtx", "_scm.mtx", ".mdim", ".ixs"):
+            assert open(str(out / "merged_blocks") + sfx, "rb").read() == open(str(tmp_path / "exp") + sfx, "rb").read(), sfx
+            os.remove(str(out / "merged_blocks") + sfx)
     stems = sorted({f.rsplit(".", 1)[0] for f in os.listdir(out)})
     assert stems == [f"1_{b}_{b}" for b in range(NBLOCKS) if b != 3]
     for b in (1, 5):
