@@ -15,11 +15,11 @@ N > 1 (torchrun, one rank per GPU): BASELINE.json config 4, the whole-chromosome
 product's block driver (ci-gwas_amd/run_blocks.py: `cusk_blockset_*`, longest-processing-time assignment; the blocks of
 a rank run in batches -- `cusk_blockset_run_batch`: correlation build, stage one, prune, stage two and reduction of all
 blocks of a batch in one set of device runs; .bed staged in HBM once per GPU), no collective in the data path.  Files
-(--writer merge, the default): every rank writes the files of its own blocks, and the merged skeleton -- what
-`merge-block-outputs` reads of every block -- is gathered to rank 0 over RCCL (the one exchange north_star names), which
-writes merged_blocks* from memory; the gather and rank 0's writing are timed separately.  --writer rank0 gathers the full
-results and lets rank 0 write every file; --writer local has no exchange (what the reference's one-process-per-block runs
-do).  Every line reports all three.  One step = one pass of the job over the whole chromosome.
+(--writer rank0, the default): the per-block results are gathered to rank 0 over RCCL (the one exchange north_star names),
+which writes every file; the gather and rank 0's writing are timed separately.  --writer merge: every rank writes the
+files of its own blocks and the merged skeleton -- what `merge-block-outputs` reads of every block -- is gathered to rank
+0, which writes merged_blocks* from memory (the library's merge); --writer local has no exchange (what the reference's
+one-process-per-block runs do).  Every line reports all three.  One step = one pass of the job over the whole chromosome.
 
 EVERY line (N = 1 included) carries the same `scale` object -- the whole-chromosome job on this many GPUs, 25 blocks per
 GPU -- and `scale.blocks_per_sec` is the key a scaling curve is to be built from (at N = 1 `value` is the headline block,
@@ -378,11 +378,11 @@ def main():
     ap.add_argument("--blocks-per-gpu", type=int, default=25, help="chromosome workload: LD blocks per GPU (config C4: 200 on 8 GPUs)")
     ap.add_argument("--inflight", type=int, default=1, help="chromosome workload: blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
-    ap.add_argument("--writer", choices=["merge", "local", "rank0"], default="merge",
-                    help="chromosome workload: merge = every rank writes the files of its own blocks and the merged skeleton is gathered to "
-                         "rank 0 over RCCL and written there (merged_blocks*: north_star's gather of the merged adjacency); rank0 = one gather "
-                         "of the full results, rank 0 writes every file; local = every rank writes its own blocks' files, no exchange.  All "
-                         "three are measured, this one is the line's blocks_per_sec")
+    ap.add_argument("--writer", choices=["rank0", "merge", "local"], default="rank0",
+                    help="chromosome workload: rank0 = one gather of the full results over RCCL, rank 0 writes every file; merge = every rank "
+                         "writes the files of its own blocks and the merged skeleton (what merge-block-outputs reads of every block) is "
+                         "gathered to rank 0 and written there as merged_blocks*; local = every rank writes its own blocks' files, no "
+                         "exchange.  All three are measured, this one is the line's blocks_per_sec")
     ap.add_argument("--batch-vars", type=int, default=16384,
                     help="chromosome workload: blocks run in batches of at most this many padded variables (0: one block per engine run)")
     ap.add_argument("--scale-steps", type=int, default=5, help="N = 1: timed passes of the whole-chromosome leg (the `scale` object)")

@@ -426,7 +426,11 @@ extern "C" int cusk_merge_packed(const char *blockfile, const void *buf, size_t 
             in[at].adj = adj[at].data();
             in[at].corr = corr[at].data();
         }
+        const auto tm0 = std::chrono::steady_clock::now();
         merge_blocks_to_files(in, sizes, basepath);
+        if (std::getenv("CUSK_BATCH_PROF"))
+            std::fprintf(stderr, "[mergeprof] %zu blocks, %zu bytes: total %.0f us\n", listed.size(), bytes,
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tm0).count());
     }
     catch (const std::exception &ex)
     {

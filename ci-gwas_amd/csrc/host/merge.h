@@ -14,6 +14,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -24,79 +25,116 @@ namespace host {
 // f"{numpy.float32(v)}" as the reference's write_mm prints it (merge_blocks.py:309-318): numpy scalars format through
 // Python's float, i.e. repr(float(v)) -- the shortest digits that round-trip the DOUBLE value, positional when the decimal
 // exponent lies in [-4, 16), else scientific with at least two exponent digits
-inline std::string python_float_str(float v)
+inline void append_python_float(std::string &out, float v)
 {
-    if (v != v) return "nan";
-    if (v == std::numeric_limits<float>::infinity()) return "inf";
-    if (v == -std::numeric_limits<float>::infinity()) return "-inf";
-    if (v == 0.0f) return std::signbit(v) ? "-0.0" : "0.0";
-    char buf[64];
-    auto r = std::to_chars(buf, buf + sizeof(buf), (double)v, std::chars_format::scientific);  // shortest round-trip digits
-    const std::string sci(buf, r.ptr);
-    const bool neg = sci[0] == '-';
-    const size_t epos = sci.find('e');
-    const std::string mant = sci.substr(neg ? 1 : 0, epos - (neg ? 1 : 0));
-    const int e10 = std::atoi(sci.c_str() + epos + 1);
-    if (e10 < -4 || e10 >= 16) return sci;  // (to_chars writes the exponent as Python does: sign, at least two digits)
-    std::string digits;
-    for (char c : mant)
-        if (c != '.') digits.push_back(c);
-    std::string out = neg ? "-" : "";
+    if (v != v)
+    {
+        out += "nan";
+        return;
+    }
+    if (v == std::numeric_limits<float>::infinity() || v == -std::numeric_limits<float>::infinity())
+    {
+        out += (v > 0 ? "inf" : "-inf");
+        return;
+    }
+    if (v == 0.0f)
+    {
+        out += std::signbit(v) ? "-0.0" : "0.0";
+        return;
+    }
+    char buf[40];
+    const auto r = std::to_chars(buf, buf + sizeof(buf) - 1, (double)v, std::chars_format::scientific);  // shortest round-trip digits
+    *r.ptr = 0;
+    const char *p = buf, *end = r.ptr;
+    if (*p == '-')
+    {
+        out += '-';
+        p++;
+    }
+    const char *e = end;
+    while (e > p && *(e - 1) != 'e') e--;  // e points behind the 'e'
+    const int e10 = std::atoi(e);
+    const char *mend = e - 1;  // mantissa = [p, mend): d or d.ddd
+    if (e10 < -4 || e10 >= 16)
+    {  // (to_chars writes the exponent as Python does: sign, at least two digits)
+        out.append(p, (size_t)(end - p));
+        return;
+    }
+    char digits[24];
+    int nd = 0;
+    for (const char *q = p; q < mend; q++)
+        if (*q != '.') digits[nd++] = *q;
     if (e10 >= 0)
     {
-        const size_t ip = (size_t)e10 + 1;  // digits before the point
-        if (digits.size() <= ip)
+        const int ip = e10 + 1;  // digits before the point
+        if (nd <= ip)
         {
-            out += digits;
-            out.append(ip - digits.size(), '0');
+            out.append(digits, (size_t)nd);
+            out.append((size_t)(ip - nd), '0');
             out += ".0";
         }
         else
         {
-            out += digits.substr(0, ip);
-            out += ".";
-            out += digits.substr(ip);
+            out.append(digits, (size_t)ip);
+            out += '.';
+            out.append(digits + ip, (size_t)(nd - ip));
         }
     }
     else
     {
         out += "0.";
         out.append((size_t)(-e10 - 1), '0');
-        out += digits;
+        out.append(digits, (size_t)nd);
     }
-    return out;
 }
 
-// insertion-ordered (row, column) -> value store with the update / delete semantics of a Python dict
+// Insertion-ordered (row, column) -> value store with the update / delete semantics of a Python dict.  Keys that involve a
+// marker are unique to their block (merged marker indices grow from block to block), so only the trait x trait keys can
+// be hit twice: those are found through a small dense table, everything else is appended without a look-up (a hash map
+// over all 40,000 correlation entries of a 25-block batch cost 10 ms).
 template <typename V>
 struct OrderedEntries
 {
-    std::vector<std::pair<uint64_t, V>> items;
-    std::vector<char> alive;
-    std::unordered_map<uint64_t, size_t> pos;
-    static uint64_t key(int64_t i, int64_t j) { return ((uint64_t)i << 32) | (uint32_t)j; }
+    struct Item
+    {
+        int64_t i, j;
+        V v;
+        char alive;
+    };
+    std::vector<Item> items;
+    int64_t np1 = 0;            // keys with i < np1 and j < np1 go through the table
+    std::vector<long long> at;  // np1 x np1: position in items, -1 = absent
+    size_t live = 0;
+    void init(int64_t num_phen)
+    {
+        np1 = num_phen + 1;
+        at.assign((size_t)(np1 * np1), -1);
+    }
+    bool small(int64_t i, int64_t j) const { return i >= 0 && j >= 0 && i < np1 && j < np1; }
     void put(int64_t i, int64_t j, V v)
     {
-        const uint64_t k = key(i, j);
-        auto it = pos.find(k);
-        if (it == pos.end())
+        if (small(i, j))
         {
-            pos.emplace(k, items.size());
-            items.emplace_back(k, v);
-            alive.push_back(1);
+            long long &p = at[(size_t)(i * np1 + j)];
+            if (p >= 0)
+            {
+                items[(size_t)p].v = v;
+                return;
+            }
+            p = (long long)items.size();
         }
-        else
-            items[it->second].second = v;
+        items.push_back(Item{i, j, v, 1});
+        live++;
     }
-    bool has(int64_t i, int64_t j) const { return pos.count(key(i, j)) != 0; }
-    void drop(int64_t i, int64_t j)
+    bool has_small(int64_t i, int64_t j) const { return small(i, j) && at[(size_t)(i * np1 + j)] >= 0; }
+    void drop_small(int64_t i, int64_t j)
     {
-        auto it = pos.find(key(i, j));
-        if (it == pos.end()) return;
-        alive[it->second] = 0;
-        pos.erase(it);
+        long long &p = at[(size_t)(i * np1 + j)];
+        if (p < 0) return;
+        items[(size_t)p].alive = 0;
+        p = -1;
+        live--;
     }
-    size_t size() const { return pos.size(); }
 };
 
 struct MergeInput
@@ -107,13 +145,20 @@ struct MergeInput
     const float *corr = nullptr;
 };
 
+inline void append_int(std::string &out, long long v)
+{
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v);
+    out.append(buf, r.ptr);
+}
+
 // blocks: one entry per line of the .blocks file, in file order (absent: the block wrote no files);
 // block_sizes: markers of every listed block.  Writes <basepath>_sam.mtx, _scm.mtx, .mdim, .ixs.
 inline void merge_blocks_to_files(const std::vector<MergeInput> &blocks, const std::vector<size_t> &block_sizes, const std::string &basepath)
 {
     OrderedEntries<int> sam;
     OrderedEntries<float> scm;
-    std::map<int64_t, int64_t> gmi;  // merged marker index -> global (.bim row) index
+    std::vector<int> gmi;  // global (.bim row) index of every selected marker (merged marker indices are unique: a plain list)
     int64_t sel_off = 0, glob_off = 0;
     size_t last_p = 0, last_ml = 0;
     bool any = false;
@@ -126,6 +171,13 @@ inline void merge_blocks_to_files(const std::vector<MergeInput> &blocks, const s
             continue;
         }
         const int64_t nv = (int64_t)b.num_var, np_ = (int64_t)b.num_phen, nm = nv - np_;
+        if (!any)
+        {
+            sam.init(np_);
+            scm.init(np_);
+        }
+        else if ((size_t)np_ != last_p)
+            die("blocks with different numbers of traits cannot be merged");
         // :24-32: block-local index (markers first, then traits) -> merged 1-based index (traits first)
         auto merged = [&](int64_t d) { return d < nm ? d + sel_off + np_ + 1 : d - nm + 1; };
         if (index == 0)
@@ -136,14 +188,11 @@ inline void merge_blocks_to_files(const std::vector<MergeInput> &blocks, const s
         }
         else
         {
-            // :336-341 (0-based i, j < num_p against 1-based keys: links of the last trait are never intersected)
-            OrderedEntries<int> have;
-            for (int64_t r = 0; r < nv; r++)
-                for (int64_t c = 0; c < nv; c++)
-                    if (b.adj[r * nv + c] != 0) have.put(merged(r), merged(c), 1);
-            for (int64_t i = 0; i < np_; i++)
-                for (int64_t j = 0; j < np_; j++)
-                    if (sam.has(i, j) && !have.has(i, j)) sam.drop(i, j);
+            // :336-341 (0-based i, j < num_p against 1-based keys: links of the last trait are never intersected); the
+            // block's own keys with i, j < num_p are its adjacency among the traits 1 .. num_p - 1
+            for (int64_t i = 1; i < np_; i++)
+                for (int64_t j = 1; j < np_; j++)
+                    if (sam.has_small(i, j) && b.adj[(nm + i - 1) * nv + (nm + j - 1)] == 0) sam.drop_small(i, j);
             // :343-345
             for (int64_t r = 0; r < nv; r++)
                 for (int64_t c = 0; c < nv; c++)
@@ -160,8 +209,7 @@ inline void merge_blocks_to_files(const std::vector<MergeInput> &blocks, const s
                 const float v = b.corr[r * nv + c];
                 if (v != 0.0f) scm.put(merged(r), merged(c), v);  // (np.nonzero: NaN counts as non-zero)
             }
-        for (int64_t d = 0; d < nv; d++)  // :54-72
-            if (merged(d) >= np_ + 1) gmi[merged(d)] = (int64_t)b.ixs[d] + glob_off;
+        for (int64_t d = 0; d < nm; d++) gmi.push_back(b.ixs[d] + (int)glob_off);  // :54-72
         sel_off += nm;
         glob_off += (int64_t)block_sizes[index];
         last_p = b.num_phen;
@@ -169,37 +217,63 @@ inline void merge_blocks_to_files(const std::vector<MergeInput> &blocks, const s
         any = true;
     }
     if (!any) die("no block output to merge");
+    const bool prof = std::getenv("CUSK_BATCH_PROF") != nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     int64_t dim = 0;  // :300-303: both headers carry the adjacency's largest row index
-    for (size_t k = 0; k < sam.items.size(); k++)
-        if (sam.alive[k]) dim = std::max<int64_t>(dim, (int64_t)(sam.items[k].first >> 32));
+    for (const auto &it : sam.items)
+        if (it.alive) dim = std::max<int64_t>(dim, it.i);
     {
         std::string out = "%%MatrixMarket matrix coordinate integer general\n";
-        out += std::to_string(dim) + "\t" + std::to_string(dim) + "\t" + std::to_string(sam.size()) + "\n";
-        for (size_t k = 0; k < sam.items.size(); k++)
-            if (sam.alive[k])
-                out += std::to_string(sam.items[k].first >> 32) + "\t" + std::to_string((uint32_t)sam.items[k].first) + "\t" +
-                       std::to_string(sam.items[k].second) + "\n";
+        out.reserve(64 + sam.live * 24);
+        append_int(out, dim), out += '\t', append_int(out, dim), out += '\t', append_int(out, (long long)sam.live), out += '\n';
+        for (const auto &it : sam.items)
+            if (it.alive) append_int(out, it.i), out += '\t', append_int(out, it.j), out += '\t', append_int(out, it.v), out += '\n';
         write_binary(basepath + "_sam.mtx", out.data(), out.size());
     }
     {
-        std::string out = "%%MatrixMarket matrix coordinate real general\n";
-        out += std::to_string(dim) + "\t" + std::to_string(dim) + "\t" + std::to_string(scm.size()) + "\n";
-        for (size_t k = 0; k < scm.items.size(); k++)
-            if (scm.alive[k])
-                out += std::to_string(scm.items[k].first >> 32) + "\t" + std::to_string((uint32_t)scm.items[k].first) + "\t" +
-                       python_float_str(scm.items[k].second) + "\n";
+        // (tens of thousands of shortest-digit conversions: a few threads format consecutive ranges of the entries)
+        std::string head = "%%MatrixMarket matrix coordinate real general\n";
+        append_int(head, dim), head += '\t', append_int(head, dim), head += '\t', append_int(head, (long long)scm.live), head += '\n';
+        const size_t ni = scm.items.size();
+        const unsigned nt = (unsigned)std::min<size_t>(16, std::max<size_t>(1, ni / 2048));
+        std::vector<std::string> part(nt);
+        auto work = [&](unsigned t) {
+            const size_t a = ni * t / nt, b = ni * (t + 1) / nt;
+            std::string &out = part[t];
+            out.reserve((b - a) * 36);
+            for (size_t k = a; k < b; k++)
+            {
+                const auto &it = scm.items[k];
+                if (!it.alive) continue;
+                append_int(out, it.i), out += '\t', append_int(out, it.j), out += '\t';
+                append_python_float(out, it.v);
+                out += '\n';
+            }
+        };
+        if (nt == 1)
+            work(0);
+        else
+        {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < nt; t++) th.emplace_back(work, t);
+            for (auto &x : th) x.join();
+        }
+        const auto tp1 = std::chrono::steady_clock::now();
+        std::string out = std::move(head);
+        for (const std::string &q : part) out += q;
         write_binary(basepath + "_scm.mtx", out.data(), out.size());
+        if (prof)
+            std::fprintf(stderr, "[mergeprof] %zu scm entries: format %.0f us, concat + write %.0f us\n", scm.live,
+                         std::chrono::duration<double, std::micro>(tp1 - tp0).count(),
+                         std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tp1).count());
     }
     {
-        const std::string out = std::to_string(sel_off + (int64_t)last_p) + "\t" + std::to_string(last_p) + "\t" + std::to_string(last_ml) + "\n";
+        std::string out;
+        append_int(out, sel_off + (long long)last_p), out += '\t', append_int(out, (long long)last_p), out += '\t', append_int(out, (long long)last_ml), out += '\n';
         write_binary(basepath + ".mdim", out.data(), out.size());
     }
-    {
-        std::vector<int> v;
-        for (const auto &kv : gmi) v.push_back((int)kv.second);
-        std::sort(v.begin(), v.end());
-        write_binary(basepath + ".ixs", v.data(), v.size());
-    }
+    std::sort(gmi.begin(), gmi.end());
+    write_binary(basepath + ".ixs", gmi.data(), gmi.size());
 }
 
 }  // namespace host

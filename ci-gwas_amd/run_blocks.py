@@ -547,7 +547,7 @@ def main(argv=None):
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL over xGMI; gloo: CPU collectives)")
     ap.add_argument("--inflight", type=int, default=1, help="blocks in flight per GPU")
     ap.add_argument("--schedule", choices=["lpt", "dynamic"], default="lpt")
-    ap.add_argument("--writer", choices=["merge", "rank0", "local"], default="merge",
+    ap.add_argument("--writer", choices=["merge", "rank0", "local"], default="rank0",
                     help="merge (batched execution): every rank writes the files of its own blocks, the merged skeleton is gathered "
                          "to rank 0 (RCCL) and written there as merged_blocks*; rank0: full results gathered to rank 0, which writes "
                          "every file; local: every rank writes its own blocks' files, no exchange")
