@@ -1323,6 +1323,7 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
 // pairs (v_pk_mul_f32 / v_pk_add_f32): the same fp32 operations in the same order per element as level1_filter, so
 // verdicts, rechecks and minima are identical to the one-position form (option l1_exp bit 1 selects that form).
 typedef float rows_f2 __attribute__((ext_vector_type(2)));
+typedef float rows_f4 __attribute__((ext_vector_type(4)));
 typedef int rows_i2u __attribute__((ext_vector_type(2), aligned(4)));
 typedef float rows_f2u __attribute__((ext_vector_type(2), aligned(4)));
 
@@ -1355,31 +1356,39 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
     extern __shared__ __attribute__((aligned(16))) float s_row[];  // LDSROW: s_row[col + sh] = C[ya, col], col >= ya
     const int n = p.n;
     const int ya = blockIdx.x;
-    if (!p.cnt->active) return;
-    const int o0 = p.off[ya];
-    const int d = p.off[ya + 1] - o0;
-    if (d == 0 || ya + 1 >= n) return;
+    if (ya + 1 >= n) return;
     if (rp.shard_world > 1 && ya % rp.shard_world != rp.shard_rank) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int kWaves = kRowsThreads >> 6;
+    const float *crow = p.C + (size_t)ya * n;
+    [[maybe_unused]] int sh = 0;
+    // LDS index = column + sh with sh = (element offset of the row) mod 4: 16-byte aligned global loads land on
+    // 16-byte aligned LDS addresses whatever n is.  Only columns >= ya are ever asked for (yb follows ya in an
+    // ascending list; idle lanes ask for ya itself).  The rounded-down head and rounded-up tail read at most three
+    // elements of the neighbouring rows (ya >= 1 whenever the head reaches back, ya <= n - 2 always).
+    // Batched runs stage the columns of the row's own block only, [ya, hi), at LDS index column - lo + sh0 (lo, the
+    // block's base, is a multiple of 64 and keeps the alignment).
+    // Every request is unconditional (a start past the end is clamped to the last 16-byte piece of the range: those lanes
+    // repeat that piece, load and store, same bytes to the same place) and the four pieces of a pass live in four named
+    // registers: with `if (iu < i_end) v[u] = ...` on an array the compiler kept the array in scratch memory and waited
+    // for each load before the next (rounds 2 and 3a: 0.31 ms for this kernel instead of 0.27).  Non-temporal: the row
+    // is read once, by this workgroup only, and should not push the neighbour lists and the selection words of the other
+    // rows out of the L2.  The first pass (all of the row up to 16 x THREADS columns) is requested right behind the
+    // per-neighbour records and before the gather that depends on them: the row streams in beside those two round trips.
+    constexpr int kStep = THREADS * 4;
+    [[maybe_unused]] const float *gbase = nullptr;
+    [[maybe_unused]] int i_first = 0, i_end = 0, i_last = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
+    [[maybe_unused]] rows_f4 v0, v1, v2, v3;
+    if (!p.cnt->active) return;
+    const int o0 = p.off[ya];
+    const int d = p.off[ya + 1] - o0;
+    if (d == 0) return;
     if (tid < 4) s_cnt[tid] = 0ull;
     int4 m = make_int4(0, 0, 0, 0);
     float mra = 0.0f;
-    if (tid < d)
-    {
-        m = rp.meta[o0 + tid];
-        mra = rp.rv[m.z + m.y];  // C[X, row]
-    }
-    const float *crow = p.C + (size_t)ya * n;
-    [[maybe_unused]] int sh = 0;
+    if (tid < d) m = rp.meta[o0 + tid];
     if constexpr (LDSROW)
     {
-        // LDS index = column + sh with sh = (element offset of the row) mod 4: 16-byte aligned global loads land on
-        // 16-byte aligned LDS addresses whatever n is.  Only columns >= ya are ever asked for (yb follows ya in an
-        // ascending list; idle lanes ask for ya itself).  The rounded-down head and rounded-up tail read at most three
-        // elements of the neighbouring rows (ya >= 1 whenever the head reaches back, ya <= n - 2 always).
-        // Batched runs stage the columns of the row's own block only, [ya, hi), at LDS index column - lo + sh0 (lo, the
-        // block's base, is a multiple of 64 and keeps the alignment).
         const size_t g0 = (size_t)ya * n;
         const int sh0 = (int)(g0 & 3);
         int lo = 0, hi = n;
@@ -1390,24 +1399,35 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
             hi = rg.y;
         }
         sh = sh0 - lo;
-        const float *gbase = p.C + (g0 - sh0) + lo;  // 16-byte aligned (p.C is: checked by the launcher)
-        const int i_end = hi - lo + sh0;
-        constexpr int kU = 4;
-        for (int i = ((ya - lo + sh0) & ~3) + tid * 4; i < i_end; i += THREADS * 4 * kU)
+        gbase = p.C + (g0 - sh0) + lo;  // 16-byte aligned (p.C is: checked by the launcher)
+        i_end = hi - lo + sh0;
+        i_last = (i_end - 1) & ~3;
+        i_first = ((ya - lo + sh0) & ~3) + tid * 4;
+        i0 = min(i_first, i_last), i1 = min(i_first + kStep, i_last), i2 = min(i_first + 2 * kStep, i_last), i3 = min(i_first + 3 * kStep, i_last);
+        v0 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i0));
+        v1 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i1));
+        v2 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i2));
+        v3 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i3));
+        asm volatile("" ::: "memory");  // the row's requests stay between the record load and its dependent gather
+    }
+    if (tid < d) mra = rp.rv[m.z + m.y];  // C[X, row]
+    if constexpr (LDSROW)
+    {
+        *reinterpret_cast<rows_f4 *>(s_row + i0) = v0;
+        *reinterpret_cast<rows_f4 *>(s_row + i1) = v1;
+        *reinterpret_cast<rows_f4 *>(s_row + i2) = v2;
+        *reinterpret_cast<rows_f4 *>(s_row + i3) = v3;
+        for (int i = i_first + kStep * 4; i < i_end; i += kStep * 4)
         {
-            float4 v[kU];
-#pragma unroll
-            for (int u = 0; u < kU; u++)
-            {
-                const int iu = i + u * THREADS * 4;
-                if (iu < i_end) v[u] = *reinterpret_cast<const float4 *>(gbase + iu);
-            }
-#pragma unroll
-            for (int u = 0; u < kU; u++)
-            {
-                const int iu = i + u * THREADS * 4;
-                if (iu < i_end) *reinterpret_cast<float4 *>(s_row + iu) = v[u];
-            }
+            i0 = min(i, i_last), i1 = min(i + kStep, i_last), i2 = min(i + 2 * kStep, i_last), i3 = min(i + 3 * kStep, i_last);
+            v0 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i0));
+            v1 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i1));
+            v2 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i2));
+            v3 = __builtin_nontemporal_load(reinterpret_cast<const rows_f4 *>(gbase + i3));
+            *reinterpret_cast<rows_f4 *>(s_row + i0) = v0;
+            *reinterpret_cast<rows_f4 *>(s_row + i1) = v1;
+            *reinterpret_cast<rows_f4 *>(s_row + i2) = v2;
+            *reinterpret_cast<rows_f4 *>(s_row + i3) = v3;
         }
         // visible to every wave after the first barrier of the staging round below
     }
