@@ -280,6 +280,184 @@ __global__ void __launch_bounds__(256) level0_wide_kernel(const float *__restric
     }
 }
 
+// The same tile with a fifth of the instructions (round 3).  The form above spends ~3,900 instructions per wave on its 64
+// elements (PMC: 1,950 vector + 2,000 scalar; the launch is bound by instruction issue at 2.3 TB/s, not by the stream):
+// per element a conditional single-lane store with its own address, the word-ownership logic, a need-bit.  Here an
+// element costs a compare (its ballot IS the bitmap word), three instructions that park the word in lane 4 rr + q, two
+// for the mirrored bit and three for "does anything of this lane need the exact comparison": the 64 words
+// of the wave leave in ONE store instruction (lane L owns word (rr, q) = (L / 4, L % 4), ownership logic evaluated
+// once per lane), and the exact pass -- entered by about one wave in 250 -- walks the flagged lanes' elements again.
+// EDGE = the tile touches the diagonal or the matrix border (index clamps and per-element validity); interior tiles
+// (nine in ten) run without either.
+template <bool EDGE>
+__device__ __forceinline__ void level0_tile(const float *__restrict__ C, unsigned long long *adj, int n, int words, float th,
+                                            float c_lo, float c_hi, int bi, int bj, int complete_graph,
+                                            unsigned long long *s_col)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i0 = bi * 64 + wave * 16, j0 = bj * kL0Cols + lane;
+    float cv[16][4];
+    if constexpr (EDGE)
+    {
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)
+        {
+            const size_t ro = (size_t)min(i0 + rr, n - 1) * n;
+#pragma unroll
+            for (int q = 0; q < 4; q++) cv[rr][q] = C[ro + min(j0 + q * 64, n - 1)];
+        }
+    }
+    else
+    {
+        const float *base = C + (size_t)i0 * n + j0;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) cv[rr][q] = base[(size_t)rr * n + q * 64];
+    }
+    // |c| within (slightly more than) the guard band <=> | |c| - mid | <= hw: the lane keeps the smallest such distance and
+    // the largest |c| it saw (|c| > 1 is where the reference's formula is not monotone) and is "flagged" by either -- a
+    // superset of the elements the exact pass decides (it applies the band test of the form above again, element by
+    // element).  NaN is never flagged: it fails `|c| < c_lo` here and every comparison of the exact form, so the edge
+    // stays either way.  (The accumulations are kept dependent chains by empty asm statements: OR-ing 64 independent
+    // terms lets the compiler build a tree at the end, which keeps all 64 ballots alive -- 700 scalar-register spills.)
+    const float mid = 0.5f * (c_lo + c_hi), hw = (c_hi - c_lo) * 0.51f + 1e-30f;
+    float dmin = 3.0e38f, amax = 0.0f;
+    unsigned wlo = 0u, whi = 0u;
+    unsigned cb[4] = {0u, 0u, 0u, 0u};  // bit 15 - rr: element (rr, q) of this lane's column goes
+#pragma unroll
+    for (int rr = 0; rr < 16; rr++)
+    {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+        {
+            const float ac = fabsf(cv[rr][q]);
+            bool rm = ac < c_lo;
+            if constexpr (EDGE)
+            {
+                const int i = i0 + rr, j = j0 + q * 64;
+                rm = rm && (i < n && j < n && i < j);
+            }
+            const unsigned long long m = __ballot(rm);
+            const bool mine = lane == rr * 4 + q;
+            wlo = mine ? (unsigned)m : wlo;
+            whi = mine ? (unsigned)(m >> 32) : whi;
+            cb[q] = (cb[q] << 1) | (rm ? 1u : 0u);
+            asm volatile("" : "+v"(cb[q]), "+v"(wlo), "+v"(whi));  // (opaque: chains stay chains, element by element)
+            dmin = fminf(dmin, fabsf(ac - mid));
+            amax = fmaxf(amax, ac);
+        }
+        asm volatile("" : "+v"(dmin), "+v"(amax));
+    }
+    {
+        // Every bitmap word has one owner except those that straddle the diagonal: word (row, w) with w > row / 64 is
+        // decided entirely here (plain store of the complete word), w < row / 64 entirely by a mirrored tile; only
+        // w == row / 64 collects bits from both sides and needs the atomic.  (With a caller-supplied starting graph
+        // the words are not all ones: atomics throughout.)
+        const int i = i0 + (lane >> 2), w = bj * 4 + (lane & 3);
+        const unsigned long long m = ((unsigned long long)whi << 32) | wlo;
+        if (m != 0ull)  // (EDGE: m is empty for rows and columns outside the matrix)
+        {
+            unsigned long long *dst = &adj[(size_t)i * words + w];
+            if (complete_graph && w != (i >> 6))
+            {
+                const int nv = n - w * 64;
+                *dst = ((nv >= 64) ? ~0ull : ((1ull << nv) - 1ull)) & ~m;
+            }
+            else
+                atomicAnd(dst, ~m);
+        }
+    }
+    const bool flagged = (dmin <= hw) || (amax > 1.0f);
+    if (__ballot(flagged) != 0ull)
+    {
+        // exact pass (uniform branch, a fraction of a percent of the waves on unrelated markers, more along the diagonal
+        // of an LD block where |c| reaches 1 + 1 ulp): which of the 64 elements -- still in registers -- need the
+        // reference's arithmetic, then only those are decided, one rolled loop as in the form above
+        unsigned need_lo = 0u, need_hi = 0u;  // bit rr * 4 + q
+        [[maybe_unused]] int j0s = j0;
+        asm volatile("" : "+v"(j0s));  // (likewise: the validity masks of the fast pass are not kept either)
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++)
+        {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+            {
+                float cq = cv[rr][q];
+                asm volatile("" : "+v"(cq));  // (a value of its own: the fast pass's 64 compare masks are not kept for this)
+                const float ac = fabsf(cq);
+                bool need = !(ac < c_lo) && !(ac > c_hi && ac <= 1.0f);  // in the band, |c| > 1, NaN
+                if constexpr (EDGE)
+                {
+                    const int i = i0 + rr, j = j0s + q * 64;
+                    need = need && (i < n && j < n && i < j);
+                }
+                if (rr * 4 + q < 32)
+                    need_lo |= need ? (1u << ((rr * 4 + q) & 31)) : 0u;
+                else
+                    need_hi |= need ? (1u << ((rr * 4 + q) & 31)) : 0u;
+                asm volatile("" : "+v"(need_lo), "+v"(need_hi));
+            }
+        }
+        // this wave's plain stores above are performed before the read-modify-writes below touch the same words
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        unsigned long long nm = ((unsigned long long)need_hi << 32) | need_lo;
+        while (nm != 0ull)
+        {
+            const int e = __builtin_ctzll(nm);
+            nm &= nm - 1ull;
+            const int rr = e >> 2, q = e & 3;
+            const int i = i0 + rr, j = j0 + q * 64;
+            const float c = C[(size_t)i * n + j];
+            if (z_below<false>(c, th))
+            {
+                atomicAnd(&adj[(size_t)i * words + bj * 4 + q], ~(1ull << lane));  // j % 64 == lane
+                atomicOr(&s_col[q * 64 + lane], 1ull << (wave * 16 + rr));
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+        if (cb[q]) atomicOr(&s_col[q * 64 + lane], (unsigned long long)(__brev(cb[q]) >> 16) << (wave * 16));
+}
+
+__global__ void __launch_bounds__(256) level0_wide2_kernel(const float *__restrict__ C, unsigned long long *adj, int n, int words,
+                                                            float th, float c_lo, float c_hi, int col_tiles, int complete_graph)
+{
+    __shared__ unsigned long long s_col[kL0Cols];
+    // tile (bi, bj): rows [64 bi, +64), columns [256 bj, +256); only tiles that reach right of the diagonal
+    int bi = 0, t = blockIdx.x;
+    for (;;)
+    {
+        // row block bi has col_tiles - (bi / 4) column tiles (its first one contains the diagonal)
+        const int len = col_tiles - (bi >> 2);
+        if (t < len) break;
+        t -= len;
+        bi++;
+    }
+    const int bj = (bi >> 2) + t;
+    s_col[threadIdx.x] = 0ull;
+    __syncthreads();
+    const bool interior = (bj * kL0Cols > bi * 64 + 63) && (bi * 64 + 64 <= n) && (bj * kL0Cols + kL0Cols <= n);
+    if (interior)
+        level0_tile<false>(C, adj, n, words, th, c_lo, c_hi, bi, bj, complete_graph, s_col);
+    else
+        level0_tile<true>(C, adj, n, words, th, c_lo, c_hi, bi, bj, complete_graph, s_col);
+    __syncthreads();
+    {
+        const unsigned long long m = s_col[threadIdx.x];
+        const int jj = bj * kL0Cols + threadIdx.x;
+        if (m != 0ull && jj < n)
+        {
+            unsigned long long *dst = &adj[(size_t)jj * words + bi];
+            if (complete_graph && bi != (jj >> 6))
+                *dst = ~m;  // all 64 rows of block bi lie above row jj and exist
+            else
+                atomicAnd(dst, ~m);
+        }
+    }
+}
+
 hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, unsigned long long *adj, int n, int words,
                          float th, int *asym_flag, hipStream_t st)
 {
@@ -300,8 +478,13 @@ hipError_t launch_level0(const float *C, const float *Ness, const int *Ginit, un
         const int col_tiles = (n + kL0Cols - 1) / kL0Cols;
         long long nt = 0;
         for (int bi = 0; bi < tiles; bi++) nt += col_tiles - (bi >> 2);
-        hipLaunchKernelGGL(level0_wide_kernel, dim3((unsigned)nt), block, 0, st, C, adj, n, words, th, c_lo, c_hi, col_tiles,
-                           Ginit == nullptr ? 1 : 0);
+        static const bool old_form = std::getenv("CUSK_L0_OLD") != nullptr;  // (A/B timing of the round-2 form)
+        if (old_form)
+            hipLaunchKernelGGL(level0_wide_kernel, dim3((unsigned)nt), block, 0, st, C, adj, n, words, th, c_lo, c_hi, col_tiles,
+                               Ginit == nullptr ? 1 : 0);
+        else
+            hipLaunchKernelGGL(level0_wide2_kernel, dim3((unsigned)nt), block, 0, st, C, adj, n, words, th, c_lo, c_hi, col_tiles,
+                               Ginit == nullptr ? 1 : 0);
     }
     else if (Ness && asym_flag)
         hipLaunchKernelGGL((level0_kernel<true, true>), grid, block, 0, st, C, Ness, adj, n, words, th, c_lo, c_hi, tiles,

@@ -211,6 +211,45 @@ def test_edge_cases(cg, eng, oracle):
     assert np.array_equal(G, ref.G) and level == ref.level
 
 
+@pytest.mark.parametrize("n", [257, 700, 1100])
+def test_level0_guard_band_and_unusual_values(cg, eng, oracle, n):
+    """Level 0 alone (cal_Indepl0, cuPC-S.cu:458-484) on a matrix whose elements crowd the decision boundary: the kernel
+    settles |c| against tanh(th) outside a guard band and leaves the band, |c| > 1 (where 0.5 |log |(1+c)/(1-c)|| comes
+    back down: c = 100 is "independent") and NaN to the reference's arithmetic.  n covers border-only tilings (257) and
+    tilings with interior tiles (700, 1100), whose code path carries no index clamps."""
+    rng = np.random.default_rng(n)
+    Th = cg.threshold_array(1000, 0.01)
+    t = float(np.tanh(Th[0]))
+    Cm = rng.uniform(-0.3, 0.3, (n, n)).astype(np.float32)
+    iu = np.triu_indices(n, 1)
+    k = len(iu[0])
+    v = Cm[iu]
+    # a third of the pairs within 1e-3 (relative) of the boundary, a few hundred within a few ulps of it
+    near = rng.random(k) < 0.33
+    v[near] = (t * (1 + rng.uniform(-1e-3, 1e-3, near.sum())) * rng.choice([-1, 1], near.sum())).astype(np.float32)
+    ulp = rng.choice(k, 400, replace=False)
+    steps = rng.integers(-6, 7, 400)
+    base = np.full(400, t, np.float32)
+    for _ in range(6):
+        base = np.where(steps > 0, np.nextafter(base, np.float32(1)), np.where(steps < 0, np.nextafter(base, np.float32(0)), base))
+        steps = steps - np.sign(steps)
+    v[ulp] = base * rng.choice([-1, 1], 400).astype(np.float32)
+    odd = rng.choice(k, 300, replace=False)
+    v[odd] = rng.choice(np.array([1, -1, 1.0000001, -1.0000001, 1.5, -3, 100, -1e6, np.nan, np.inf, -np.inf, 0, -0.0], np.float32), 300)
+    Cm[iu] = v
+    Cm.T[iu] = v
+    np.fill_diagonal(Cm, 1)
+    Cm = np.ascontiguousarray(Cm)
+    ref = oracle.skeleton(Cm, Th, 0)
+    Cd = cg.DeviceArray(Cm)
+    st = eng.run_skeleton(Cd.ptr, n, Th, 0)
+    G = eng.adjacency()
+    Cd.free()
+    assert st.level == ref.level
+    assert np.array_equal(G, ref.G)
+    assert 0 < int(G.sum()) < n * (n - 1)
+
+
 @pytest.mark.parametrize("mode", ["skeleton", "hetcor", "het"])
 def test_fast_filter_never_contradicts_exact_path(cg, oracle, synth, mode):
     """validate mode evaluates BOTH paths for every certified verdict: zero contradictions,
