@@ -1538,6 +1538,9 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
     __shared__ unsigned long long s_cnt[4];
     extern __shared__ __attribute__((aligned(16))) float s_row[];  // LDSROW: s_row[col + sh] = C[ya, col], col >= ya
     const int n = p.n;
+    // (Rows to XCDs, tried in round 3: XCD x takes the x-th and (15 - x)-th sixteenth of the rows instead of every eighth
+    // row, so that an L2 keeps re-reading the lists of one region: 0.387 ms against 0.255.  Consecutive rows running at the
+    // same time on all XCDs already share their lists in time, and whole regions per XCD unbalance dense and sparse ones.)
     const int ya = blockIdx.x;
     if (ya + 1 >= n) return;
     if (rp.shard_world > 1 && ya % rp.shard_world != rp.shard_rank) return;
@@ -1989,23 +1992,23 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     rp.exp = exp;
     rp.shard_rank = shard_rank;
     rp.shard_world = shard_world;
+    const bool two = !(exp & 1) && !(exp & 2);  // two list positions per lane (default); bit 1: the one-position form
     const dim3 grid((unsigned)((exp & 2) ? ((n + 7) / 8) * 8 : n));
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
-    const bool two = !(exp & 1) && !(exp & 2);  // two list positions per lane (default); bit 1: the one-position form
-    // Row of C in LDS (4 (n + 8) bytes per workgroup).  The workgroup size grows with n so that a CU keeps its waves
-    // while fewer rows fit into its 160 KB: of 256 / 512 threads the size that puts most waves on a CU (at most 20:
-    // 93 VGPRs), the smaller one on a tie; when two rows do not fit (n > ~16,000) or the matrix is not 16-byte aligned
-    // the row is gathered through L1/L2.  exp bit 32 forces the gather form, bits 64 / 128 / 256
-    // force 512 / 1024 / 256 threads.
+    // Row of C in LDS (4 (n + 8) bytes per workgroup).  Of 256 / 512 threads the size that puts most ROWS on a CU (at most
+    // 20 waves: 99 VGPRs), the larger one on a tie: a row's prologue is a chain of four dependent round trips during which
+    // its waves have nothing to do, and only other rows on the CU fill that time.  When two rows do not fit (n > ~16,000)
+    // or the matrix is not 16-byte aligned the row is gathered through L1/L2.  exp bit 32 forces the gather form, bits
+    // 64 / 128 / 256 force 512 / 1,024 / 256 threads.
     const size_t row_lds = sizeof(float) * ((size_t)(p.row_range ? p.max_span : n) + 8);
     constexpr size_t kLdsCu = 160 * 1024;
     int threads = 0;
     if (two && !(exp & 32) && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)
     {
-        int best_waves = 0;
-        // measured at n = 10,020 (gather form 0.336 ms): 512 threads 0.313, 256 threads 0.316, 384 threads (six waves per
-        // row) 0.373, 1,024 threads (one row per CU) 0.408 -- so the LDS form is only taken while two rows fit (n <= ~16,000)
+        int best_wgs = 0, best_waves = 0;
+        // measured at n = 10,020, round 3 (gather form 0.336 ms): 256 threads (three rows per CU) 0.255, 512 threads (two
+        // rows) 0.263, 384 threads (three rows, six waves each) 0.312, 1,024 threads (one row per CU) 0.383
         for (int t : {256, 512, 1024})
         {
             const size_t fixed = sizeof(int4) * t + sizeof(int) * (2 * t + 1) + sizeof(int) * 2 * (t / 64) + 64;
@@ -2013,9 +2016,10 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
             const int waves = wgs * (t / 64);
             const bool forced = ((exp & 64) && t == 512) || ((exp & 128) && t == 1024) || ((exp & 256) && t == 256);
             if (t == 1024 && !forced) continue;
-            if (wgs >= (forced ? 1 : 2) && (waves > best_waves || forced))
+            if (wgs >= (forced ? 1 : 2) && (wgs > best_wgs || (wgs == best_wgs && waves > best_waves) || forced))
             {
-                best_waves = forced ? 1000 : waves;
+                best_wgs = forced ? 1000 : wgs;
+                best_waves = waves;
                 threads = t;
             }
         }
