@@ -75,7 +75,7 @@ def roofline_of(level, tests, subsets, n, kernel_ms, engine, traffic=None):
         ab = algorithmic_bytes(level, tests, subsets, n)
         ach = ab / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         return {
-            "kernel": f"level1_rows2_kernel<{mode}, false, 512, true> (one launch per step; the gather form <.., 256, false> when two rows of C "
+            "kernel": f"level1_rows2_kernel<{mode}, false, 256, true> (one launch per step; <.., 512, true> where that puts as many rows on a CU; the gather form <.., 256, false> when two rows of C "
                       f"do not fit a CU's LDS)" if level == 1 else "level0_wide_kernel",
             "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
             "traffic": traffic, "algorithmic_bytes_per_step": ab, "kernel_ms_per_step": float(kernel_ms),

@@ -28,14 +28,25 @@ python3 - "$O" "$TAG" <<'PY'
 import csv, glob, sys, collections, json
 O, TAG = sys.argv[1], sys.argv[2]
 acc = collections.defaultdict(lambda: [0.0, 0])
+rows = []
 for f in glob.glob(O + "/pmc*/**/*counter_collection.csv", recursive=True):
-    for r in csv.DictReader(open(f)):
-        k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
-        acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
+    rows += list(csv.DictReader(open(f)))
+# a kernel is also launched on the small problems of the run (parity check, second stages): only the launches with the
+# kernel's largest grid -- the headline block -- are averaged
+big = collections.defaultdict(int)
+for r in rows:
+    kn = r["Kernel_Name"].split("(")[0]
+    big[kn] = max(big[kn], int(r["Grid_Size"]))
+for r in rows:
+    kn = r["Kernel_Name"].split("(")[0]
+    if int(r["Grid_Size"]) != big[kn]:
+        continue
+    k = (kn, r["Counter_Name"])
+    acc[k][0] += float(r["Counter_Value"]); acc[k][1] += 1
 with open(f"{O}/{TAG}_pmc_summary.txt", "w") as out:
     out.write("rocprofv3 --pmc <set> --kernel-trace -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-chromosome  (MI355X, three separate passes:\n"
               "FETCH_SIZE | WRITE_SIZE | SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE)\n"
-              "per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them\n\n")
+              "per-launch averages over the launches with the kernel's largest grid (the headline block); FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them\n\n")
     last = None
     for (kn, cn), (v, c) in sorted(acc.items()):
         if kn != last:
@@ -45,11 +56,11 @@ def per_launch(kpat):
     f = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "FETCH_SIZE"]
     w = [v / c for (kn, cn), (v, c) in acc.items() if kpat in kn and cn == "WRITE_SIZE"]
     return (f[0] if f else 0.0) * 1024, (w[0] if w else 0.0) * 1024
-K1 = "level1_rows2_kernel<0, false, 512, true>"
+K1 = "level1_rows2_kernel<0, false, 256, true>"
 f1, w1 = per_launch(K1)
 # calibration (MI355X_MICROARCH.md: "calibrate on a known byte count in your own access pattern"): the level-0 kernel
 # streams the upper triangle of the 10020^2 fp32 matrix once with the same 4-byte-per-lane coalesced loads
-f0, _ = per_launch("level0_wide_kernel")
+f0, _ = per_launch("level0_wide2_kernel")
 n0 = 10020
 known0 = 4.0 * n0 * (n0 - 1) / 2
 cal = known0 / f0 if f0 > 0 else 1.0
@@ -58,7 +69,7 @@ json.dump({"level1": f1 * 2.0 + w1, "level1_guide_x2": f1 * 2.0 + w1, "level1_ca
            "level0_fetch_reported": f0, "level0_known_bytes": known0, "kernel": K1,
            "note": "HBM-side bytes per launch of " + K1 + ", separate PMC passes (" + TAG + "): FETCH_SIZE x 1024 x correction + WRITE_SIZE x 1024. "
                    "`level1` (what bench.py prints as roofline.traffic) uses the guide's gfx950 correction, FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM: "
-                   "128-byte requests tallied at 64 bytes); `level1_calibrated` uses this run's own calibration instead: level0_wide_kernel reads a known " +
+                   "128-byte requests tallied at 64 bytes); `level1_calibrated` uses this run's own calibration instead: level0_wide2_kernel reads a known " +
                    str(int(known0)) + " bytes (upper triangle, 4-byte-per-lane coalesced loads) and FETCH_SIZE reports 1/fetch_calibration of them"},
           open(f"{O}/pmc_traffic.json", "w"), indent=1)
 PY
