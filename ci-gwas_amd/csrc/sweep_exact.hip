@@ -267,7 +267,7 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
     {
         const int o0 = p.off[row];
         const int d = p.off[row + 1] - o0;
-        int removed = 0;
+        int removed = 0, dec = 0;
         // sets without a given member: C(d, L) - C(d - 1, L - 1) (0 for rows with fewer than L + 1 neighbours)
         unsigned long long never = 0;
         if (d > L) never = p.binom[(size_t)d * kBinomStride + L] - p.binom[(size_t)(d - 1) * kBinomStride + (L - 1)];
@@ -287,32 +287,19 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
                     r = p.best[o0 + k];
             }
             const int Y = valid ? p.nbr[o0 + k] : 0;
-            // The edge row - Y goes when EITHER side found a separating set.  Every wave only ever
-            // touches its own row of the bitmap and its own degree, so no returning atomics are needed:
-            // the other side's verdict is looked up (position of `row` in Y's ascending list).
+            // The edge row - Y goes when EITHER side found a separating set.
             bool gone = (r != kNone);
-            if (valid && !gone && p.meta != nullptr)
+            if (p.meta != nullptr)
             {
-                const int4 m = p.meta[o0 + k];
-                gone = p.sel != nullptr ? (p.sel[m.z + m.y] != 0xffffffffu) : (p.best[m.z + m.y] != kNone);
-            }
-            else if (valid && !gone)
-            {
-                const int oy = p.off[Y];
-                int lo = 0, hi = p.off[Y + 1] - oy;
-                while (lo < hi)
+                // level 1 behind the row-streaming kernel: the other side's verdict is one look-up away (meta holds the
+                // position of `row` in Y's list), every wave only touches its own bitmap row and its own degree, no atomics
+                if (valid && !gone)
                 {
-                    const int mid = (lo + hi) >> 1;
-                    if (p.nbr[oy + mid] < row)
-                        lo = mid + 1;
-                    else
-                        hi = mid;
+                    const int4 m = p.meta[o0 + k];
+                    gone = p.sel != nullptr ? (p.sel[m.z + m.y] != 0xffffffffu) : (p.best[m.z + m.y] != kNone);
                 }
-                gone = (p.best[oy + lo] != kNone);  // adjacency is symmetric at level start: nbr[oy+lo] == row
-            }
-            // clear the bits: the wave owns this bitmap row, and the Y of a list ascend, so the lanes that share a
-            // 64-bit word are contiguous -> segmented OR over the wave, one plain read-modify-write per word
-            {
+                // clear the bits: the Y of a list ascend, so the lanes that share a 64-bit word are contiguous ->
+                // segmented OR over the wave, one plain read-modify-write per word
                 const int w = valid ? (Y >> 6) : -1 - lane;
                 unsigned long long bits = gone ? (1ull << (Y & 63)) : 0ull;
 #pragma unroll
@@ -324,6 +311,24 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
                 }
                 const int pw = __shfl_up(w, 1);
                 if (valid && bits != 0ull && (lane == 0 || pw != w)) p.adj[(size_t)row * p.words + w] &= ~bits;
+            }
+            else if (__ballot(gone) != 0ull)
+            {
+                // levels >= 2 (a few removals per level): the slot that found a set clears BOTH bits of the edge with
+                // returning atomics, and whoever actually cleared a bit takes the edge off that row's degree -- exactly once
+                // per row and edge when both sides found a set, and nothing on a redo of the level (the bits are gone).
+                // (Round 2 had every surviving slot look the other side's verdict up with a binary search in Y's list:
+                // eight dependent loads per wave at every level.)
+                int mine = 0;
+                if (gone)
+                {
+                    const unsigned long long bY = 1ull << (Y & 63), bR = 1ull << (row & 63);
+                    const unsigned long long o1 = atomicAnd(&p.adj[(size_t)row * p.words + (Y >> 6)], ~bY);
+                    const unsigned long long o2 = atomicAnd(&p.adj[(size_t)Y * p.words + (row >> 6)], ~bR);
+                    mine = (o1 & bY) ? 1 : 0;
+                    if (o2 & bR) atomicSub(&p.deg[Y], 1);
+                }
+                dec += __popcll(__ballot(mine != 0));
             }
             removed += __popcll(__ballot(gone));
             found += __popcll(__ballot(r != kNone));
@@ -345,7 +350,12 @@ __global__ void __launch_bounds__(256) gather_records_kernel(FinalizeParams p)
 #pragma unroll
             for (int a = 0; a < L; a++) p.rec_s[(size_t)a * p.rec_cap + slot] = p.nbr[o0 + idx[a]];
         }
-        if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
+        if (p.meta != nullptr)
+        {
+            if (lane == 0) p.deg[row] = d - removed;  // absolute, so a redo of the level is idempotent
+        }
+        else if (lane == 0 && dec)
+            atomicSub(&p.deg[row], dec);
     }
     // cusk_stats.removed: ordered pairs that received a separating set at this level; cusk_stats.canonical_tests
     for (int o = 32; o > 0; o >>= 1) canon += __shfl_xor(canon, o);
