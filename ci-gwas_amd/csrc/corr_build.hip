@@ -915,6 +915,288 @@ __global__ void __launch_bounds__(64 * kMxpWaves) mxp_mfma_kernel(const unsigned
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the same three sums on the bf16 matrix pipe (16x the rate of the f32 form above, whose 8 + 8 K = 2 products
+// per 16 individuals bound the kernel at 0.41 ms for 13,700 markers x 20 traits -- as long as the 64 x more work of the
+// SNP x SNP kernel of a batch).  A trait value is split EXACTLY into three bf16 pieces, y = hi + mid + lo (8 + 8 + 8
+// significant bits), the dosage {0, 1, 2} and the flags {0, 1} are bf16 numbers anyway, so every product is exact in f32
+// and only the order of the f32 additions differs from the chain above (the reference's own order is that of its block
+// reduction, corr_kernels.cu:157-238; the bar is its test tolerance, 1e-5: tests/test_gpu_parity.py).
+//   B fragments (mxp_split_kernel, once per build): bf16 columns c = q * 21 + t for piece q of trait t (columns 0..62),
+//     64 + t = NaN flag of trait t, 85 = 1 for every individual < N; zero beyond N (padded to 64 individuals), so the
+//     padding bits of a .bed row never count whatever they decode to; stored fragment-major (see the kernel).
+//   Workgroup = 4 waves (one per SIMD, so that a wave may hold 160 accumulator registers) = split-K over the individuals,
+//     TWO marker tiles of 32 per wave (they share the B fragments:
+//     half the L2 traffic; with a tile table the two tiles may belong to different blocks of a batch -- the traits are the
+//     same for all).  Per 16 individuals and tile: G x P0, G x P1, V x P0, V x P1, V x F = five
+//     v_mfma_f32_32x32x16_bf16.  A fragment of a lane (marker r32, half kh): individuals 8 kh .. 8 kh + 7 = two bytes of
+//     the row; a nibble (two 2-bit codes) becomes one dword of two bf16 through v_perm_b32 with the code as byte selector
+//     into a 4-entry table (low bytes in one source, high bytes in the other): 6 vector instructions per dword pair (g, v).
+//   The four partial tiles are added in a fixed order through LDS (deterministic), then every thread finishes a few
+//   (marker, trait) pairs: pieces summed (hi + mid) + lo, r = (sum g y - mean_g sum y) / (n sd_g).
+// ---------------------------------------------------------------------------------------------------------------
+typedef __bf16 mxb_bf8 __attribute__((ext_vector_type(8)));
+typedef unsigned mxb_u4 __attribute__((ext_vector_type(4)));
+constexpr int kMxbTraits = 21;  // traits per launch: 3 x 21 piece columns <= 64, 21 flags + the ones column <= 32
+constexpr int kMxbCols = 96;
+constexpr int kMxbOnes = 64 + kMxbTraits;
+constexpr int kMxbWaves = 4;  // one wave per SIMD: two marker tiles x five products = 160 accumulator registers per wave
+
+// One thread per (column tile k, group g, lane): the 16 bytes that lane (column k * 32 + (lane & 31), half lane >> 5) of a
+// wave feeds to the MFMA of group g -- eight consecutive individuals of one column -- stored at ((k * G + g) * 64 + lane) * 8,
+// so a wave's fragment load is one contiguous kilobyte.  G = groups, a multiple of four (the kernel requests four at a time).
+__global__ void __launch_bounds__(256) mxp_split_kernel(const float *__restrict__ phen, size_t N, size_t G, size_t p0, int pc,
+                                                         unsigned short *__restrict__ Bq)
+{
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= 3 * G * 64) return;
+    const int lane = (int)(id & 63);
+    const size_t g = (id >> 6) % G;
+    const int k = (int)((id >> 6) / G);
+    const int c = k * 32 + (lane & 31);
+    const size_t i0 = g * 16 + 8 * (size_t)(lane >> 5);
+    // column c: piece q of trait t (c = q * 21 + t < 63), NaN flag of trait c - 64, the ones column, or nothing
+    const int q = c < 63 ? c / kMxbTraits : -1;
+    const int t = c < 63 ? c % kMxbTraits : c - 64;
+    unsigned short out[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+    {
+        const size_t i = i0 + j;
+        unsigned short v = 0;
+        if (i < N)
+        {
+            if (c == kMxbOnes)
+                v = 0x3f80;  // 1.0
+            else if (c != 63 && c < kMxbOnes && t < pc)
+            {
+                const float y = phen[(p0 + t) * N + i];
+                if (q < 0)
+                    v = (y != y) ? 0x3f80 : 0;
+                else if (y == y)
+                {
+                    const float hi = __uint_as_float(__float_as_uint(y) & 0xffff0000u);
+                    const float r1 = (hi - hi == 0.0f) ? y - hi : 0.0f;  // exact; an infinite value stays in the first piece
+                    const float mid = __uint_as_float(__float_as_uint(r1) & 0xffff0000u);
+                    const float r2 = r1 - mid;  // exact, at most 8 significant bits
+                    v = (unsigned short)(__float_as_uint(q == 0 ? hi : (q == 1 ? mid : r2)) >> 16);
+                }
+            }
+        }
+        out[j] = v;
+    }
+    mxb_u4 o;
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = (unsigned)out[2 * j] | ((unsigned)out[2 * j + 1] << 16);
+    *reinterpret_cast<mxb_u4 *>(Bq + id * 8) = o;
+}
+
+struct MxbTile
+{
+    long long c_off;    // element offset of the block's matrix inside C
+    long long mxp_off;  // element offset of the block's rows inside mxp
+    long long row0;     // first marker row of the block in the .bed / mean / sd arrays
+    int m, tile32, valid, pad;
+};
+
+template <bool FAST>
+__global__ void __launch_bounds__(64 * kMxbWaves) mxp_bf16_kernel(const unsigned char *__restrict__ bed, const unsigned short *__restrict__ Bq,
+                                                        const float *__restrict__ mean, const float *__restrict__ sd, float *C,
+                                                        float *mxp, size_t m_in, size_t G, size_t p, size_t clb, size_t n,
+                                                        size_t p0, int pcount, int ntiles, const int2 *__restrict__ mtile,
+                                                        const CorrBatchBlock *__restrict__ bblk)
+{
+    __shared__ float s_red[kMxbWaves][16][64];  // the partial copies of one accumulator tile
+    __shared__ float s_out[2][5][32][33];  // reduced tiles: [marker tile][product][marker][column]
+    __shared__ MxbTile s_tile[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r32 = lane & 31, kh = lane >> 5;
+    if (tid < 2)
+    {
+        MxbTile t;
+        const int T = 2 * (int)blockIdx.x + tid;
+        t.valid = T < ntiles ? 1 : 0;
+        t.c_off = 0;
+        t.mxp_off = 0;
+        t.row0 = 0;
+        t.m = (int)m_in;
+        t.tile32 = T;
+        t.pad = 0;
+        if (t.valid && mtile != nullptr)
+        {  // batched build: tile mtile[T].y of block mtile[T].x
+            const int2 mt = mtile[T];
+            const CorrBatchBlock bb = bblk[mt.x];
+            t.row0 = (long long)bb.bed_row0;
+            t.c_off = (long long)bb.base * (long long)n + bb.base;
+            t.mxp_off = (long long)bb.mxp_off * (long long)p;
+            t.m = bb.m;
+            t.tile32 = mt.y;
+        }
+        s_tile[tid] = t;
+    }
+    __syncthreads();
+    const unsigned char *rowp[2];
+    bool mok[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+    {
+        const MxbTile t = s_tile[u];
+        const long long mk = (long long)t.tile32 * 32 + r32;
+        mok[u] = t.valid && mk < t.m;
+        rowp[u] = bed + (size_t)(t.row0 + (mok[u] ? mk : 0)) * clb;
+    }
+    v16f acc[2][5];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) acc[u][a][r] = 0.0f;
+
+    // the wave's range of groups, in fours (G is a multiple of four)
+    const size_t gper = ((G / 4 + kMxbWaves - 1) / kMxbWaves) * 4;
+    const size_t g_begin = min(G, (size_t)wave * gper), g_end = min(G, g_begin + gper);
+    const unsigned short *bq = Bq + (size_t)lane * 8;
+    // FAST (rows of the .bed block 16-byte aligned): the four dwords of four consecutive groups in one request per marker
+    // row -- a request of 64 lanes in 64 different rows costs the address unit one cycle per lane whatever its width
+    auto fetch_a4 = [&](int u, size_t g0, unsigned (&w)[4]) {
+        if constexpr (FAST)
+        {
+            const mxb_u4 v = reinterpret_cast<const mxb_u4 *>(rowp[u])[g0 >> 2];
+            w[0] = v[0], w[1] = v[1], w[2] = v[2], w[3] = v[3];
+        }
+        else
+        {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                unsigned x = 0u;
+                for (size_t bb = 0; bb < 4; bb++) x |= (unsigned)(((g0 + j) * 4 + bb < clb) ? rowp[u][(g0 + j) * 4 + bb] : 0x55u) << (8 * bb);
+                w[j] = x;
+            }
+        }
+    };
+    auto fetch_b = [&](size_t g, mxb_u4 (&b)[3]) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) b[k] = *reinterpret_cast<const mxb_u4 *>(bq + ((size_t)k * G + g) * 512);
+    };
+    // eight 2-bit codes -> eight bf16 dosages and eight bf16 non-missing flags
+    // code 00 -> dosage 2 (0x4000), 01 -> missing (0, flag 0), 10 -> 1 (0x3f80), 11 -> 0; flag 1.0 = 0x3f80
+    auto decode = [&](unsigned x, mxb_u4 &ag, mxb_u4 &av) {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+            const unsigned nib = x >> (4 * j);
+            const unsigned t = (nib & 3u) | ((nib & 0xcu) << 14);  // c0 | c1 << 16
+            const unsigned sel = t * 0x0101u + 0x04000400u;        // bytes [c0, 4 + c0, c1, 4 + c1]: low byte, high byte per value
+            ag[j] = __builtin_amdgcn_perm(0x003f0040u, 0x00800000u, sel);
+            av[j] = __builtin_amdgcn_perm(0x3f3f003fu, 0x80800080u, sel);
+        }
+    };
+    auto multiply = [&](const unsigned (&w)[2], const mxb_u4 (&b)[3]) {
+        const mxb_bf8 b0 = __builtin_bit_cast(mxb_bf8, b[0]), b1 = __builtin_bit_cast(mxb_bf8, b[1]), b2 = __builtin_bit_cast(mxb_bf8, b[2]);
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+        {
+            const unsigned x = mok[u] ? ((w[u] >> (16 * kh)) & 0xffffu) : 0x5555u;
+            mxb_u4 ag, av;
+            decode(x, ag, av);
+            const mxb_bf8 g8 = __builtin_bit_cast(mxb_bf8, ag), v8 = __builtin_bit_cast(mxb_bf8, av);
+            acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g8, b0, acc[u][0], 0, 0, 0);
+            acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g8, b1, acc[u][1], 0, 0, 0);
+            acc[u][2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v8, b0, acc[u][2], 0, 0, 0);
+            acc[u][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v8, b1, acc[u][3], 0, 0, 0);
+            acc[u][4] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v8, b2, acc[u][4], 0, 0, 0);
+        }
+    };
+    if (g_begin < g_end)
+    {
+        // One loop body, four groups (64 individuals) per trip: the operands of the following four are requested
+        // (clamped, unconditional) before the forty products of the current four and handed over by register moves.  (An
+        // exit in the middle of an unrolled pair makes the compiler keep two copies of the 160 accumulator registers and
+        // move them at every join.)  The first form asked for one dword per lane and group and for B columns N apart: five
+        // requests of 64 scattered addresses per group and wave kept the address unit busier than the products kept the
+        // matrix pipe (184 us); now two scattered 16-byte requests and twelve contiguous kilobytes per four groups.
+        unsigned wc[2][4], wn[2][4];
+        mxb_u4 bc[4][3], bn[4][3];
+        auto fetch4 = [&](size_t g0, unsigned (&w)[2][4], mxb_u4 (&bb)[4][3]) {
+            fetch_a4(0, g0, w[0]);
+            fetch_a4(1, g0, w[1]);
+#pragma unroll
+            for (int j = 0; j < 4; j++) fetch_b(g0 + j, bb[j]);
+        };
+        fetch4(g_begin, wc, bc);
+        for (size_t g = g_begin; g < g_end; g += 4)
+        {
+            fetch4(min(g + 4, g_end - 4), wn, bn);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                const unsigned wj[2] = {wc[0][j], wc[1][j]};
+                multiply(wj, bc[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+            {
+                wc[0][j] = wn[0][j];
+                wc[1][j] = wn[1][j];
+#pragma unroll
+                for (int kk = 0; kk < 3; kk++) bc[j][kk] = bn[j][kk];
+            }
+        }
+    }
+    // ---- split-K reduction, tile by tile, waves 0, 1, ... in that order ----
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+        {
+            __syncthreads();
+#pragma unroll
+            for (int r = 0; r < 16; r++) s_red[wave][r][lane] = acc[u][a][r];
+            __syncthreads();
+            for (int e = tid; e < 16 * 64; e += 64 * kMxbWaves)
+            {
+                const int r = e >> 6, l = e & 63;
+                float v = s_red[0][r][l];
+#pragma unroll
+                for (int wv = 1; wv < kMxbWaves; wv++) v += s_red[wv][r][l];
+                // C/D layout: column = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+                s_out[u][a][(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31] = v;
+            }
+        }
+    __syncthreads();
+    // ---- every thread finishes a few (tile, marker, trait) triples ----
+    for (int idx = tid; idx < 2 * 32 * pcount; idx += 64 * kMxbWaves)
+    {
+        const int t = idx % pcount, i = (idx / pcount) & 31, u = idx / (pcount * 32);
+        const MxbTile tt = s_tile[u];
+        const long long mi = (long long)tt.tile32 * 32 + i;
+        if (!tt.valid || mi >= tt.m) continue;
+        float sgy[3], svy[3];
+#pragma unroll
+        for (int q = 0; q < 3; q++)
+        {
+            const int c = q * kMxbTraits + t;
+            sgy[q] = s_out[u][c >> 5][i][c & 31];
+            svy[q] = s_out[u][2 + (c >> 5)][i][c & 31];
+        }
+        const float gy = (sgy[0] + sgy[1]) + sgy[2], vy = (svy[0] + svy[1]) + svy[2];
+        const float cnt = s_out[u][4][i][kMxbOnes - 64] - s_out[u][4][i][t];
+        const size_t mg = (size_t)(tt.row0 + mi);
+        const float rr = (gy - mean[mg] * vy) / (cnt * sd[mg]);
+        const size_t tg = p0 + (size_t)t;
+        if (C)
+        {
+            float *Cb = C + tt.c_off;
+            Cb[(size_t)mi * n + (size_t)tt.m + tg] = rr;
+            Cb[((size_t)tt.m + tg) * n + (size_t)mi] = rr;
+        }
+        if (mxp) mxp[(size_t)tt.mxp_off + (size_t)mi * p + tg] = rr;
+    }
+}
+
 // one workgroup per trait pair (a < b): corr_kernels.cu:285-343
 __global__ void __launch_bounds__(256) pxp_kernel(const float *__restrict__ phen, float *C, size_t m, size_t N, size_t p,
                                                    size_t n)
@@ -1078,7 +1360,30 @@ int corr_build_impl(cusk_engine *e, const unsigned char *bed, const float *phen,
         if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[2], s));
     }
     if (!ahead) CUSK_HIP(e, hipEventRecord(e->ev_corr[3], s));
-    for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
+    const bool mxp_bf16 = !e->opt_corr_popcount && !e->opt_corr_mxp_f32 && p > 0;
+    if (mxp_bf16)
+    {
+        // the bf16 form: exact three-piece split of the traits, 21 traits per launch
+        const size_t G = (N + 63) / 64 * 4;  // groups of 16 individuals, in fours
+        CUSK_HIP(e, e->mxp_bq.ensure(sizeof(unsigned short) * kMxbCols * G * 16));
+        const bool fast = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_d) & 15u) == 0);
+        const int ntiles = (int)((m + 31) / 32);
+        for (size_t p0 = 0; p0 < p; p0 += kMxbTraits)
+        {
+            const int pc = (int)std::min<size_t>(kMxbTraits, p - p0);
+            hipLaunchKernelGGL(mxp_split_kernel, dim3((unsigned)((3 * G * 64 + 255) / 256)), dim3(256), 0, s, phen_d, N, G, p0, pc,
+                               e->mxp_bq.as<unsigned short>());
+            if (fast)
+                hipLaunchKernelGGL(mxp_bf16_kernel<true>, dim3((unsigned)((ntiles + 1) / 2)), dim3(64 * kMxbWaves), 0, s, bed_d,
+                                   e->mxp_bq.as<unsigned short>(), mean_d, std_d, C_dev, mxp_d, m, G, p, clb, n, p0, pc, ntiles,
+                                   (const int2 *)nullptr, (const CorrBatchBlock *)nullptr);
+            else
+                hipLaunchKernelGGL(mxp_bf16_kernel<false>, dim3((unsigned)((ntiles + 1) / 2)), dim3(64 * kMxbWaves), 0, s, bed_d,
+                                   e->mxp_bq.as<unsigned short>(), mean_d, std_d, C_dev, mxp_d, m, G, p, clb, n, p0, pc, ntiles,
+                                   (const int2 *)nullptr, (const CorrBatchBlock *)nullptr);
+        }
+    }
+    for (size_t p0 = 0; p0 < p && !mxp_bf16; p0 += kMaxPhenRegs)
     {
         const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
         if (e->opt_corr_popcount)
@@ -1246,7 +1551,29 @@ int corr_build_batch_impl(cusk_engine *e, int phase, const unsigned char *bed_de
         const bool fast = (clb % 4 == 0) && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(bed_dev) & 3u) == 0) &&
                           ((reinterpret_cast<uintptr_t>(phen_dev) & 15u) == 0);
         const int2 *mt_d = reinterpret_cast<const int2 *>(d + o_t);
-        for (size_t p0 = 0; p0 < p; p0 += kMaxPhenRegs)
+        const bool mxp_bf16 = !e->opt_corr_mxp_f32;
+        if (mxp_bf16)
+        {
+            const size_t G = (N + 63) / 64 * 4;
+            CUSK_HIP(e, e->mxp_bq.ensure(sizeof(unsigned short) * kMxbCols * G * 16));
+            const bool fastb = (clb % 16 == 0) && ((reinterpret_cast<uintptr_t>(bed_dev) & 15u) == 0);
+            const int ntiles = (int)tiles2.size();
+            for (size_t p0 = 0; p0 < p; p0 += kMxbTraits)
+            {
+                const int pc = (int)std::min<size_t>(kMxbTraits, p - p0);
+                hipLaunchKernelGGL(mxp_split_kernel, dim3((unsigned)((3 * G * 64 + 255) / 256)), dim3(256), 0, s, phen_dev, N, G, p0, pc,
+                                   e->mxp_bq.as<unsigned short>());
+                if (fastb)
+                    hipLaunchKernelGGL(mxp_bf16_kernel<true>, dim3((unsigned)((ntiles + 1) / 2)), dim3(64 * kMxbWaves), 0, s, bed_dev,
+                                       e->mxp_bq.as<unsigned short>(), mean_dev, std_dev, C_dev, mxp_d, (size_t)0, G, p, clb, n, p0, pc,
+                                       ntiles, mt_d, blk_d);
+                else
+                    hipLaunchKernelGGL(mxp_bf16_kernel<false>, dim3((unsigned)((ntiles + 1) / 2)), dim3(64 * kMxbWaves), 0, s, bed_dev,
+                                       e->mxp_bq.as<unsigned short>(), mean_dev, std_dev, C_dev, mxp_d, (size_t)0, G, p, clb, n, p0, pc,
+                                       ntiles, mt_d, blk_d);
+            }
+        }
+        for (size_t p0 = 0; p0 < p && !mxp_bf16; p0 += kMaxPhenRegs)
         {
             const size_t pc = std::min<size_t>(kMaxPhenRegs, p - p0);
             if (fast)

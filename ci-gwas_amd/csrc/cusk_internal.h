@@ -135,6 +135,7 @@ struct cusk_engine
     int opt_vec = 1;
     int opt_overlap = 1;
     int opt_corr_popcount = 0;
+    int opt_corr_mxp_f32 = 0;  // 1: SNP x trait on the f32 matrix instructions (round 1-2 form) instead of the bf16 split
     int opt_assume_symmetric = 0;
     long long opt_queue_cap = 4ll << 20;
     int opt_hostprof = 0;
@@ -163,7 +164,7 @@ struct cusk_engine
     size_t shard_host_cap = 0;
 
     // correlation build scratch
-    cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev, pxp_dev;
+    cusk::DevBuf bed_dev, phen_dev, mean_dev, std_dev, planes, mxp_dev, pxp_dev, mxp_bq;
     cusk::DevBuf corr_tab[2];  // batched build: block / tile tables of phase one (marker x trait) and two (marker x marker)
     void *corr_tab_pinned[2] = {nullptr, nullptr};
     size_t corr_tab_pinned_cap[2] = {0, 0};

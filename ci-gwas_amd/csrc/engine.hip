@@ -899,7 +899,7 @@ extern "C" void cusk_engine_destroy(cusk_engine *e)
     for (DevBuf *b : {&e->adj, &e->adj0, &e->deg, &e->binom, &e->counters, &e->ti, &e->queue,
                       &e->rv, &e->rpos, &e->sel, &e->wpre, &e->rec_x, &e->rec_y, &e->rec_l, &e->rec_s, &e->den_x, &e->den_y, &e->den_l,
                       &e->den_z, &e->den_s, &e->den_counts, &e->den_off, &e->off1, &e->planblk, &e->scratch_a, &e->scratch_b, &e->bed_dev, &e->phen_dev,
-                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev})
+                      &e->mean_dev, &e->std_dev, &e->planes, &e->mxp_dev, &e->mxp_bq})
         b->release();
     for (int k = 0; k < 2; k++)
     {
@@ -948,6 +948,8 @@ extern "C" int cusk_engine_set_option(cusk_engine *e, const char *key, long long
         e->opt_overlap = (int)value;
     else if (k == "corr_popcount")
         e->opt_corr_popcount = (int)value;
+    else if (k == "corr_mxp_f32")
+        e->opt_corr_mxp_f32 = (int)value;
     else if (k == "assume_symmetric")
         e->opt_assume_symmetric = (int)value;
     else if (k == "queue_capacity" && value > 0)

@@ -126,7 +126,8 @@ const char *cusk_last_error(const cusk_engine *e);
  * four-tests-per-ds_read_b128 sweep kernel; 0: scalar fast kernel), "overlap" (default 1: independent degree
  * classes and the winners' exact z run on an auxiliary stream), "corr_fp4" (default 1: the SNP x SNP contingency GEMMs of
  * cusk_corr_build on the FP4 matrix pipe; 0: the int8 MFMA form), "corr_popcount" (default 0; 1: bit-plane AND/popcount
- * cross-check kernels instead of the matrix cores), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
+ * cross-check kernels instead of the matrix cores), "corr_mxp_f32" (default 0: SNP x trait sums on the bf16 matrix pipe with every
+ * trait value split exactly into three bf16 pieces; 1: the f32 matrix instructions of rounds 1-2), "assume_symmetric" (default 0: level 0 verifies C == C^T bitwise;
  * 1: the caller guarantees it, e.g. a matrix written by cusk_corr_build), "queue_capacity" (recheck queue entries, default 4Mi), "chunk" (combination ranks per work item, default 2048), "timing" (HIP events for cusk_stats: 0 total_ms only; 1, the default, around every level's sweep: kernel_ms, and level_ms = end of the previous level's sweep to the end of this one's; 2 also level start / end: level_ms = plan to finaliser; 3 only the pair around the level-1 row kernel: main_kernel_ms[1] -- every event costs a few microseconds of device time), "chunk0" (conditioning sets per work item of the first degree class, default 512), "tmaj_min_level" (first level swept by unions T = S + Y, one inverse per l + 1 tests: default 6, 99 = never; single threshold and symmetric matrix only), "tmaj_validate_stride" (with "validate": the union-major sweep checks the unions whose per-lane count is a multiple of this power of two against double precision; default 1 = all), "hostprof" (1: host-side phase marks of every run on stderr), "max_staged_classes" (test hook: at most this many degree classes keep their sub-matrix in LDS; 0 sends every row through the kernels of the unstaged class), "chunk0_low" (work-item size of the first degree class at levels 2-4, default 256), "vec_threads" (workgroup size of the vectorised sweep for the first degree class: 64, 128 or 256; default 64), "lookahead" (levels the host enqueues ahead of the level counters it has seen, default 2; every kernel checks its level's gate on the device), "sync2" (default 1: the host reads level 2's gate record -- class counts, maximum degree -- before it enqueues that level's sweeps, so that degree classes that turn out empty are not launched at levels >= 2; 0: enqueue ahead on the level-1 degree bound), "item_capacity" (work items per degree class and level the buffers hold before the engine grows them and takes the level up again, default 1Mi), "sepselect_ws_bytes" (HBM work space of
  * cusk_sepselect_greedy for candidate lists too long for LDS, default 4 GiB; such pairs run in batches of what fits). */
 int cusk_engine_set_option(cusk_engine *e, const char *key, long long value);

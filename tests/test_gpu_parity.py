@@ -342,7 +342,7 @@ def test_corr_kat_bmt(cg, kat):
         assert np.allclose(mxp2, b[mp], atol=b["tol"], rtol=0)
 
 
-@pytest.mark.parametrize("m,N,p", [(97, 1001, 3), (300, 2048, 7), (64, 130, 1)])
+@pytest.mark.parametrize("m,N,p", [(97, 1001, 3), (300, 2048, 7), (64, 130, 1), (150, 640, 45), (33, 64, 21), (70, 4096, 22)])
 def test_corr_build_vs_oracle(cg, eng, oracle, synth, m, N, p):
     bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=m, miss=0.01)
     phen = phen.copy()
@@ -385,6 +385,35 @@ def test_corr_mfma_and_popcount_kernels_agree(cg, oracle, synth, m, N):
     o_mxm, _, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
     iu = np.triu_indices(m, 1)
     assert np.array_equal(outs[0][:m, :m][iu], o_mxm, equal_nan=True)
+
+
+@pytest.mark.parametrize("m,N,p", [(200, 2048, 20), (95, 1000, 5), (64, 4160, 43)])
+def test_corr_snp_trait_bf16_split_against_f32_chain(cg, oracle, synth, m, N, p):
+    """SNP x trait on the bf16 matrix pipe (every trait value split exactly into three bf16 pieces: the default) against the
+    f32 matrix-instruction form of rounds 1-2 (option corr_mxp_f32) and the oracle: the products are exact in both, only the
+    order of the f32 additions differs.  Traits with NaN; N with and without whole 64-individual requests; more than 21
+    traits (three launches)."""
+    bed, phen, means, stds, G = synth.synth_bed_block(m, N, p, block_index=m + 1, miss=0.03)
+    phen = phen.copy()
+    phen[::53] = np.nan
+    phen[2::307] *= 1e-3  # small values next to ordinary ones: the low pieces matter
+    n = m + p
+    outs = []
+    for opts in ({}, {"corr_mxp_f32": 1}):
+        e = cg.Engine(0)
+        for k, v in opts.items():
+            e.set_option(k, v)
+        Cd = cg.DeviceArray(nbytes=4 * n * n)
+        mxp = e.corr_build(bed, phen, m, N, p, means, stds, Cd.ptr, want_mxp=True)
+        sq = Cd.download(np.float32, (n, n))
+        assert np.array_equal(sq[:m, m:], mxp.reshape(m, p), equal_nan=True) and np.array_equal(sq[m:, :m], sq[:m, m:].T, equal_nan=True)
+        outs.append(sq)
+        Cd.free()
+        e.close()
+    assert np.array_equal(outs[0][:m, :m], outs[1][:m, :m], equal_nan=True)
+    assert np.allclose(outs[0], outs[1], atol=2e-6, rtol=0, equal_nan=True)
+    _, o_mxp, _ = oracle.corr_pearson_npn(bed, phen, m, N, p, means, stds)
+    assert np.allclose(outs[0][:m, m:].ravel(), np.asarray(o_mxp).ravel(), atol=1e-5, rtol=0, equal_nan=True)
 
 
 def test_randomised_stress_against_oracle(cg, eng, oracle, synth):
