@@ -55,6 +55,35 @@ __global__ void bed_to_bitplanes_kernel(const unsigned char *__restrict__ bed, u
     planes[(2 * m + mk) * w64 + w] = bv;
 }
 
+// sin(x) in double precision for the arguments this file has, |x| <= pi/2 (x = pi/2 tau): the two kernel polynomials of
+// fdlibm (k_sin.c / k_cos.c, error < 1 ulp) and sin x = sign(x) cos(pi/2 - |x|) above pi/4, the difference formed from the
+// two-part pi/2 of e_rem_pio2.c.  The library routine spends ~300 double-precision instructions per call on the general
+// argument reduction; sixteen calls per lane made the epilogue of the SNP x SNP kernels as long as 64 K-blocks of matrix
+// products.  The result is rounded to float by the caller: it can differ from the library's only where the two doubles
+// straddle a float rounding boundary, as the library's own last bit already may against the host's libm (the oracle).
+// NaN stays NaN; anything outside the range (rounding can put |tau| a few ulps above 1) goes to the library.
+__device__ __forceinline__ double sin_quarter_turn(double x)
+{
+    const double ax = fabs(x);
+    if (!(ax <= 1.6)) return sin(x);
+    if (ax <= 0.78539816339744830962)
+    {
+        const double z = x * x, v = z * x;
+        const double r = 8.33333333332248946124e-03 +
+                         z * (-1.98412698298579493134e-04 +
+                              z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+        return x + v * (-1.66666666666666324348e-01 + z * r);
+    }
+    const double y = (1.57079632679489655800e+00 - ax) + 6.12323399573676603587e-17;
+    const double z = y * y;
+    const double r = z * (4.16666666666666019037e-02 +
+                          z * (-1.38888888888741095749e-03 +
+                               z * (2.48015872894767294178e-05 +
+                                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+    const double c = 1.0 - (0.5 * z - z * r);
+    return x < 0.0 ? -c : c;
+}
+
 // tau-b -> sin(pi/2 tau) in the reference's fp32 operation order (corr_kernels.cu:544-564)
 __device__ __forceinline__ float npn_from_counts(const float *s)
 {
@@ -65,7 +94,7 @@ __device__ __forceinline__ float npn_from_counts(const float *s)
     float u = ((s[0] * (s[3] + s[6])) + (s[1] * (s[4] + s[7])) + (s[2] * (s[5] + s[8])) + (s[3] * s[6]) + (s[4] * s[7]) +
                (s[5] * s[8]));
     float kendall = (p - q) / sqrtf((p + q + t) * (p + q + u));
-    return (float)sin(M_PI / 2 * (double)kendall);
+    return (float)sin_quarter_turn(M_PI / 2 * (double)kendall);
 }
 
 // counts for a 32 x 32 tile of marker pairs (upper triangle of tiles), 2 x 2 pairs per thread

@@ -10,6 +10,7 @@
 // run_cusk_block (block_pipeline.h) -- the files are byte-identical (tests/test_gpu_batch.py) -- because the blocks never
 // interact: a row only meets columns of its own block.
 #pragma once
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 
@@ -301,13 +302,23 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     // reduce_sepsets does, including the stage-two remap quirk: a member s (an index of the stage-two
     // space) is looked up in a map keyed by the STAGE-ONE index of the retained variables
     {
-        for (int k = 0; k < K; k++)
+        // the dense k x k x 14 arrays of the blocks (megabytes of -1, fresh pages) are filled by helper threads while this
+        // one waits for the records to arrive from the device
+        std::vector<std::thread> fillers;
         {
-            Reduced &out = outs[(size_t)kept[(size_t)k]].r;
-            out.S.assign(out.num_var * out.num_var * (size_t)ML, -1);
+            const int nth = std::min(3, K);
+            for (int t = 0; t < nth; t++)
+                fillers.emplace_back([&, t, nth]() {
+                    for (int k = t; k < K; k += nth)
+                    {
+                        Reduced &out = outs[(size_t)kept[(size_t)k]].r;
+                        out.S.assign(out.num_var * out.num_var * (size_t)ML, -1);
+                    }
+                });
         }
         const int *x = nullptr, *y = nullptr, *rs = nullptr;  // engine-owned pinned memory
         const long long cnt = cusk_result_sepsets_view(e, &x, &y, &rs);
+        for (auto &th : fillers) th.join();
         if (cnt < 0) engine_die("sepsets (batch)", e);
         if (cnt > 0)
         {
