@@ -128,6 +128,28 @@ class BlockSet:
         return br, st
 
 
+    def run_block_to_files(self, eng: Engine, i: int, outdir: str, next_block: int = -1):
+        """One block the way `mps cusk` runs it (cli.cpp:521-677): pipeline, then the five result files written by the library
+        straight from its result (no copy into numpy arrays).  -> (written: bool, CuskBlockStats, seconds spent writing)"""
+        import time
+
+        res = C.c_void_p()
+        st = CuskBlockStats()
+        rc = lib().cusk_blockset_run_block_next(self.h, eng.h, int(i), int(next_block), C.byref(res), C.byref(st))
+        if rc != 0:
+            raise RuntimeError(f"block {i}: {lib().cusk_blockset_last_error().decode()}")
+        if not res:
+            return False, st, 0.0
+        try:
+            t0 = time.perf_counter()
+            if lib().cusk_block_result_write(res, outdir.encode()) != 0:
+                raise RuntimeError(f"block {i}: {lib().cusk_blockset_last_error().decode()}")
+            dt = time.perf_counter() - t0
+        finally:
+            lib().cusk_block_result_free(res)
+        return True, st, dt
+
+
 class BatchResult:
     """cusk_batch_result of include/cusk_hip.h: the reduced results of the blocks of one batch, owned by the library"""
 

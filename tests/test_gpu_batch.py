@@ -206,6 +206,29 @@ def test_batch_result_accessors_and_oracle(chromosome, oracle, tmp_path):
     bs.close()
 
 
+def test_run_block_to_files_writes_what_mps_cusk_writes(chromosome, tmp_path):
+    """BlockSet.run_block_to_files (pipeline + the library's own file writer, what bench.py's end-to-end block figure
+    times) leaves, block by block, the five files per-block `mps cusk` runs left; a block without signal writes nothing"""
+    from cigwas_amd import run_blocks as rb
+    from cigwas_amd.skeleton import Engine
+
+    bs = rb.BlockSet(chromosome["phen"], chromosome["stem"], chromosome["blocks"], float(ALPHA), int(L1), int(L2), int(DEPTH))
+    e = Engine(0)
+    out = tmp_path / "o"
+    out.mkdir()
+    sig = chromosome["signal"]
+    quiet = [i for i in range(len(chromosome["bounds"])) if i not in sig][0]
+    for b in (sig[0], quiet, sig[-1]):
+        written, st, secs = bs.run_block_to_files(e, b, str(out))
+        assert written == (b in sig) and secs >= 0.0
+    assert len(os.listdir(out)) == 10
+    for f in os.listdir(out):
+        assert open(out / f, "rb").read() == open(os.path.join(str(chromosome["ref"]), f), "rb").read(), f
+    rb.lib().cusk_blockset_release_engine(bs.h, e.h)
+    e.close()
+    bs.close()
+
+
 @pytest.mark.timeout(900)
 def test_two_ranks_batched_over_gloo(chromosome, tmp_path):
     """the job under torchrun, two ranks sharing the GPU, batched execution, results gathered to rank 0"""

@@ -5,6 +5,18 @@ python3 -c "import torch" > /dev/null 2>&1
 timeout -k 10 600 python3 bench.py --steps 20 --warmup 3 > $O/bench.log 2>&1 && grep '^{' $O/bench.log > $O/${TAG}_bench.json
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o t -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/trace.log 2>&1)
 cp $(find $O/trace -name '*kernel_stats.csv' | head -1) $O/${TAG}_bench_kernel_stats.csv
+# the same trace, per kernel and GRID: a kernel that also runs on the small problems of the process (parity run of the
+# oracle-sized block, second stages of the end-to-end block) averages over unlike launches in the stats file above
+python3 - "$(find $O/trace -name '*kernel_trace.csv' | head -1)" > $O/${TAG}_bench_kernel_stats_by_grid.csv <<'PY'
+import csv, sys, collections
+acc = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(sys.argv[1])):
+    k = (r["Kernel_Name"].split("(")[0], int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"])), int(r["Workgroup_Size_X"]))
+    acc[k][0] += 1; acc[k][1] += int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+print("Name,Workgroups,WorkgroupSize,Calls,TotalDurationNs,AverageNs")
+for (kn, g, w), (c, t) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+    print(f'"{kn}",{g},{w},{c},{int(t)},{t / c:.1f}')
+PY
 # the hetcor engine on the same block (bench.py --engine cuskss): bench line + kernel stats
 timeout -k 10 600 python3 bench.py --engine cuskss --steps 20 --warmup 3 --no-chromosome > $O/bench_cuskss.log 2>&1 && grep '^{' $O/bench_cuskss.log > $O/${TAG}_bench_cuskss.json
 (cd /tmp && export TMPDIR=/tmp && timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ss -o t -- python3 $R/bench.py --engine cuskss --steps 20 --warmup 3 --no-cpu-baseline --no-chromosome > $O/trace_ss.log 2>&1)
