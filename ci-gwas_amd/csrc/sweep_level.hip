@@ -1622,11 +1622,15 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
     const bool use_filter = rp.use_filter != 0;
     const float th = p.th, t2 = p.t2, beta = rp.beta;
     unsigned ntests = 0, nrem = 0, viol = 0;
+    const bool count_by_segment = (MODE == 0) || !rp.has_ti;
     for (int kc = 0; kc < d; kc += kRowsChunk)
     {
         // ---- lay the non-empty segments of this round end to end, counted in pairs of positions ----
         const int len = (kc + tid < d) ? max(0, m.w - m.y - 1) : 0;
         const int plen = (len + 1) >> 1;
+        // executed tests: without a time-index rule every position of a segment is tested in both directions -- counted
+        // here once per segment instead of four flag additions per lane and step
+        if (count_by_segment) ntests += 2u * (unsigned)len;
         int pos = (plen > 0) ? 1 : 0, pre = plen;
         for (int o = 1; o < 64; o <<= 1)
         {
@@ -1765,7 +1769,7 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
             const bool sureA1 = ok1 && (h00a.y > 0.0f) && (passA1 || lhsA.y > hiA.y);
             const bool sureB0 = ok0 && okb && (passB0 || lhsB.x > hiB.x);
             const bool sureB1 = ok1 && okb && (passB1 || lhsB.y > hiB.y);
-            ntests += (needA0 ? 1u : 0u) + (needB0 ? 1u : 0u) + (needA1 ? 1u : 0u) + (needB1 ? 1u : 0u);
+            if (!count_by_segment) ntests += (needA0 ? 1u : 0u) + (needB0 ? 1u : 0u) + (needA1 ? 1u : 0u) + (needB1 ? 1u : 0u);
             const bool slowA0 = needA0 && (VALIDATE || !sureA0), slowB0 = needB0 && (VALIDATE || !sureB0);
             const bool slowA1 = needA1 && (VALIDATE || !sureA1), slowB1 = needB1 && (VALIDATE || !sureB1);
             if (__ballot(slowA0 || slowB0 || slowA1 || slowB1) != 0ull)
