@@ -1505,6 +1505,9 @@ __global__ void __launch_bounds__(kRowsThreads) level1_rows_kernel(SweepParams p
 // (nbr, rv: 4-byte aligned dwordx2), gathers two elements of the row of C, and evaluates its four tests as float2
 // pairs (v_pk_mul_f32 / v_pk_add_f32): the same fp32 operations in the same order per element as level1_filter, so
 // verdicts, rechecks and minima are identical to the one-position form (option l1_exp bit 1 selects that form).
+#ifndef CUSK_ROWS_SETS
+#define CUSK_ROWS_SETS 5
+#endif
 typedef float rows_f2 __attribute__((ext_vector_type(2)));
 typedef float rows_f4 __attribute__((ext_vector_type(4)));
 typedef int rows_i2u __attribute__((ext_vector_type(2), aligned(4)));
@@ -1565,9 +1568,13 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
     [[maybe_unused]] const float *gbase = nullptr;
     [[maybe_unused]] int i_first = 0, i_end = 0, i_last = 0, i0 = 0, i1 = 0, i2 = 0, i3 = 0;
     [[maybe_unused]] rows_f4 v0, v1, v2, v3;
-    if (!p.cnt->active) return;
-    const int o0 = p.off[ya];
-    const int d = p.off[ya + 1] - o0;
+    // (the activity flag and the list bounds in ONE scalar round trip: left alone, the compiler waits for the flag before it
+    // asks for the bounds)
+    const int act = p.cnt->active;
+    const int o0 = p.off[ya], o1 = p.off[ya + 1];
+    asm volatile("" ::"s"(act), "s"(o0), "s"(o1));
+    if (!act) return;
+    const int d = o1 - o0;
     if (d == 0) return;
     if (tid < 4) s_cnt[tid] = 0ull;
     int4 m = make_int4(0, 0, 0, 0);
@@ -1830,29 +1837,34 @@ __global__ void __launch_bounds__(THREADS) level1_rows2_kernel(SweepParams p, Ro
                 if (headA) (void)__hip_atomic_fetch_min(&rp.sel[cur.ia], (unsigned)bsel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
         };
-        // three operand sets rotate through the stages (no register copies, so the compiler can wait for exactly
-        // the set it needs); the scheduling barriers keep the requests ahead of the evaluation
-        RowsStep2 s0, s1, s2;
-        stage_a(f_begin, s0);
-        stage_a(f_begin + 64, s1);
-        stage_b(s0);
-        for (int base = f_begin;; base += 192)
+        // Operand sets rotate through the stages (no register copies: every index below is a compile-time constant after
+        // unrolling, so the compiler can wait for exactly the set it needs); the scheduling barriers keep the requests
+        // ahead of the evaluation.  Round 3: kSets sets, the list entries requested kSets - 1 steps ahead of their
+        // evaluation (rounds 1-2: three sets, two steps ahead -- a step's ~90 vector instructions cover 300 ns, the entries
+        // take longer than two of those to arrive from L2, and the three waves of a SIMD, all the LDS rows allow, do not
+        // cover the rest: 0.254 ms; five sets 0.242; launch_level1_rows has the other depths).
+        constexpr int kSets = CUSK_ROWS_SETS;
+        RowsStep2 st[kSets];
+#pragma unroll
+        for (int j = 0; j < kSets - 1; j++) stage_a(f_begin + 64 * j, st[j]);
+        stage_b(st[0]);
+        for (int base = f_begin;; base += 64 * kSets)
         {
-            stage_a(base + 128, s2);
-            stage_b(s1);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_c(s0);
-            if (base + 64 >= f_end) break;
-            stage_a(base + 192, s0);
-            stage_b(s2);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_c(s1);
-            if (base + 128 >= f_end) break;
-            stage_a(base + 256, s1);
-            stage_b(s0);
-            __builtin_amdgcn_sched_barrier(0);
-            stage_c(s2);
-            if (base + 192 >= f_end) break;
+            bool done = false;
+#pragma unroll
+            for (int j = 0; j < kSets; j++)
+            {
+                stage_a(base + 64 * (kSets - 1 + j), st[(kSets - 1 + j) % kSets]);
+                stage_b(st[(j + 1) % kSets]);
+                __builtin_amdgcn_sched_barrier(0);
+                stage_c(st[j]);
+                if (base + 64 * (j + 1) >= f_end)
+                {
+                    done = true;
+                    break;
+                }
+            }
+            if (done) break;
         }
     }
     for (int o = 32; o > 0; o >>= 1)
@@ -2001,7 +2013,7 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     const dim3 blk(kRowsThreads);
     if (ev_begin) (void)hipEventRecord(ev_begin, st);
     // Row of C in LDS (4 (n + 8) bytes per workgroup).  Of 256 / 512 threads the size that puts most ROWS on a CU (at most
-    // 20 waves: 99 VGPRs), the larger one on a tie: a row's prologue is a chain of four dependent round trips during which
+    // 16 waves, 12 for the hetcor / validating forms: 125 / 131-137 VGPRs with five operand sets), the larger one on a tie: a row's prologue is a chain of four dependent round trips during which
     // its waves have nothing to do, and only other rows on the CU fill that time.  When two rows do not fit (n > ~16,000)
     // or the matrix is not 16-byte aligned the row is gathered through L1/L2.  exp bit 32 forces the gather form, bits
     // 64 / 128 / 256 force 512 / 1,024 / 256 threads.
@@ -2011,12 +2023,13 @@ hipError_t launch_level1_rows(int mode, bool validate, bool use_filter, const Sw
     if (two && !(exp & 32) && (reinterpret_cast<uintptr_t>(p.C) & 15) == 0)
     {
         int best_wgs = 0, best_waves = 0;
-        // measured at n = 10,020, round 3 (gather form 0.336 ms): 256 threads (three rows per CU) 0.255, 512 threads (two
-        // rows) 0.263, 384 threads (three rows, six waves each) 0.312, 1,024 threads (one row per CU) 0.383
+        // measured at n = 10,020, round 3 with three operand sets (gather form 0.336 ms): 256 threads (three rows per CU)
+        // 0.255, 512 threads (two rows) 0.263, 384 threads (three rows, six waves each) 0.312, 1,024 threads (one row per
+        // CU) 0.383; operand sets at 256 threads: 3: 0.254, 4: 0.244, 5: 0.242, 6: 0.243, 7: 0.246, 9 (two waves per SIMD): 0.328
         for (int t : {256, 512, 1024})
         {
             const size_t fixed = sizeof(int4) * t + sizeof(int) * (2 * t + 1) + sizeof(int) * 2 * (t / 64) + 64;
-            const int wgs = std::min((int)(kLdsCu / (row_lds + fixed)), 20 / (t / 64));
+            const int wgs = std::min((int)(kLdsCu / (row_lds + fixed)), ((mode == 0 && !validate) ? 16 : 12) / (t / 64));
             const int waves = wgs * (t / 64);
             const bool forced = ((exp & 64) && t == 512) || ((exp & 128) && t == 1024) || ((exp & 256) && t == 256);
             if (t == 1024 && !forced) continue;
