@@ -339,8 +339,10 @@ def e2e_block(args, bed, phen, means, stds, device):
         walls, phases = [], {}
         os.sync()  # (the input files were written a moment ago: keep their write-back out of the result files' way)
         for k in range(6):
+            outk = os.path.join(out, str(k))  # a directory of its own per run: a job writes new files, it does not truncate old ones
+            os.makedirs(outk)
             t0 = time.perf_counter()
-            _, st, wr = bs.run_block_to_files(eng, 0, out)  # (as `mps cusk` does: the library writes its own result)
+            _, st, wr = bs.run_block_to_files(eng, 0, outk)  # (as `mps cusk` does: the library writes its own result)
             t2 = time.perf_counter()
             if k:  # the first call allocates
                 walls.append((t2 - t0) * 1e3)
