@@ -372,7 +372,7 @@ extern "C" int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, 
         put(b.r.new_to_old.data(), 4 * b.r.new_to_old.size());
         put(b.r.G.data(), 4 * b.r.G.size());
         put(b.r.C.data(), 4 * b.r.C.size());
-        if (with_sep) put(b.r.S.data(), 4 * b.r.S.size());
+        if (with_sep) put(b.r.dense_sep().data(), 4 * b.r.dense_sep().size());
     }
     return CUSK_OK;
 }
@@ -486,7 +486,7 @@ extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const ch
         if (all_sep)
             write_many(items, outdir, true);
         else
-            for (const cusk_block_result *b : items) write_reduced(b->r, make_path(outdir, b->stem, ""), !b->r.S.empty());
+            for (const cusk_block_result *b : items) write_reduced(b->r, make_path(outdir, b->stem, ""), b->r.has_sep());
         if (std::getenv("CUSK_BATCH_PROF"))
             std::fprintf(stderr, "[writeprof] %zu blocks, %zu bytes: parse %.0f us, write %.0f us\n", items.size(), bytes,
                          std::chrono::duration<double, std::micro>(t1 - t0).count(),
@@ -510,7 +510,7 @@ extern "C" const char *cusk_block_result_stem(const cusk_block_result *r) { retu
 extern "C" const int *cusk_block_result_ixs(const cusk_block_result *r) { return r ? r->r.new_to_old.data() : nullptr; }
 extern "C" const int *cusk_block_result_adj(const cusk_block_result *r) { return r ? r->r.G.data() : nullptr; }
 extern "C" const float *cusk_block_result_corr(const cusk_block_result *r) { return r ? r->r.C.data() : nullptr; }
-extern "C" const int *cusk_block_result_sep(const cusk_block_result *r) { return r ? r->r.S.data() : nullptr; }
+extern "C" const int *cusk_block_result_sep(const cusk_block_result *r) { return r ? r->r.dense_sep().data() : nullptr; }
 
 extern "C" int cusk_block_result_write(const cusk_block_result *r, const char *outdir)
 {

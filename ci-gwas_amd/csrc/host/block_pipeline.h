@@ -136,6 +136,14 @@ inline int count_significant(const float *mxp, size_t count, float th0)
 }
 
 // ReducedGC / ReducedGCS of include/mps/parent_set.h
+// One separating set of the reduced result: the cell (ix, iy) of the num_var x num_var x max_level array holds s[0 .. cnt)
+// followed by -1
+struct SepRec
+{
+    int ix, iy, cnt;
+    int s[ML];
+};
+
 struct Reduced
 {
     size_t num_var = 0, num_phen = 0, max_level = 0;
@@ -143,9 +151,57 @@ struct Reduced
     std::vector<int> G;
     std::vector<float> C;
     std::vector<float> ess;  // cuskss
-    std::vector<int> S;      // cusk: num_var^2 * max_level
+    // cusk: the separating sets, num_var^2 * max_level ints, -1 where there is none (570 retained variables: 18 MB for a
+    // few thousand sets).  The single-block pipeline keeps the sets as a sorted list (sep_sparse = true) and the dense
+    // array is only built for whoever asks for it (dense_sep); the .sep file is written without it (write_sep_streaming).
+    mutable std::vector<int> S;
+    std::vector<SepRec> sep_recs;  // ascending (ix, iy), one per cell
+    bool sep_sparse = false;
     size_t num_markers() const { return num_var - num_phen; }
+    bool has_sep() const { return sep_sparse || !S.empty(); }
+    const std::vector<int> &dense_sep() const
+    {
+        if (sep_sparse && S.empty())
+        {
+            S.assign(num_var * num_var * max_level, -1);
+            for (const SepRec &q : sep_recs)
+                std::memcpy(&S[((size_t)q.ix * num_var + (size_t)q.iy) * max_level], q.s, sizeof(int) * (size_t)q.cnt);
+        }
+        return S;
+    }
 };
+
+// The .sep file of a sparse result: the array goes out in pieces of ~1 MB that are a whole number of cells, from ONE buffer
+// of -1 that is patched with the sets of the piece and restored afterwards -- no 18 MB array to fill and to read back
+// from memory (the buffer stays in cache), same bytes.
+inline void write_sep_streaming(const std::string &path, const Reduced &r)
+{
+    FILE *f = std::fopen(path.c_str(), "wb");
+    if (!f) die("cannot write " + path);
+    const size_t ml = r.max_level, total = r.num_var * r.num_var * ml;
+    const size_t piece = ml * ((size_t)(1 << 18) / (ml ? ml : 1));  // ints
+    std::vector<int> buf(std::min(piece, total), -1);
+    size_t q = 0;
+    for (size_t c0 = 0; c0 < total; c0 += piece)
+    {
+        const size_t c1 = std::min(total, c0 + piece), q0 = q;
+        for (; q < r.sep_recs.size(); q++)
+        {
+            const SepRec &s = r.sep_recs[q];
+            const size_t base = ((size_t)s.ix * r.num_var + (size_t)s.iy) * ml;
+            if (base >= c1) break;
+            std::memcpy(&buf[base - c0], s.s, sizeof(int) * (size_t)s.cnt);
+        }
+        std::fwrite(buf.data(), sizeof(int), c1 - c0, f);
+        for (size_t z = q0; z < q; z++)
+        {
+            const SepRec &s = r.sep_recs[z];
+            const size_t base = ((size_t)s.ix * r.num_var + (size_t)s.iy) * ml;
+            for (int t = 0; t < s.cnt; t++) buf[base - c0 + (size_t)t] = -1;
+        }
+    }
+    std::fclose(f);
+}
 
 inline void write_reduced(const Reduced &r, const std::string &base, bool with_sep)
 {
@@ -156,7 +212,10 @@ inline void write_reduced(const Reduced &r, const std::string &base, bool with_s
     write_binary(base + ".ixs", r.new_to_old.data(), r.new_to_old.size());
     write_binary(base + ".adj", r.G.data(), r.G.size());
     write_binary(base + ".corr", r.C.data(), r.C.size());
-    if (with_sep) write_binary(base + ".sep", r.S.data(), r.S.size());
+    if (with_sep && r.sep_sparse && r.S.empty())
+        write_sep_streaming(base + ".sep", r);
+    else if (with_sep)
+        write_binary(base + ".sep", r.S.data(), r.S.size());
 }
 
 inline std::vector<float> gather(cusk_engine *e, const float *M_dev, int n, const std::vector<int> &P)
@@ -210,6 +269,56 @@ inline std::vector<int> reduce_sepsets(cusk_engine *e, const std::vector<int> &P
         }
     }
     return S;
+}
+
+// reduce_sepsets without the dense array: the same cells as a list in ascending (ix, iy) order.  Returns false (and leaves
+// the list empty) when two records name the same cell -- the dense form's "the later record overwrites the head of the
+// earlier" is then what the caller must reproduce (never seen: an ordered pair has one record).
+inline bool reduce_sepsets_sparse(cusk_engine *e, const std::vector<int> &P, size_t max_level, const std::vector<int> *index_map,
+                                  std::vector<SepRec> &out)
+{
+    out.clear();
+    const size_t k = P.size();
+    const int *x = nullptr, *y = nullptr, *rs = nullptr;  // engine-owned pinned memory
+    const long long cnt = cusk_result_sepsets_view(e, &x, &y, &rs);
+    if (cnt < 0) engine_die("sepsets", e);
+    if (cnt == 0) return true;
+    std::unordered_map<int, int> pos, old_to_new;
+    for (size_t i = 0; i < k; i++)
+    {
+        pos[P[i]] = (int)i;
+        old_to_new[index_map ? (*index_map)[P[i]] : P[i]] = (int)i;
+    }
+    out.reserve((size_t)cnt);
+    for (long long r = 0; r < cnt; r++)
+    {
+        auto ix = pos.find(x[r]), iy = pos.find(y[r]);
+        if (ix == pos.end() || iy == pos.end()) continue;
+        SepRec q;
+        q.ix = ix->second;
+        q.iy = iy->second;
+        q.cnt = 0;
+        for (size_t l = 0; l < max_level && l < (size_t)ML; l++)
+        {
+            const int sv = rs[(size_t)r * ML + l];
+            if (sv != -1 && pos.count(sv))
+            {
+                auto it = old_to_new.find(sv);
+                q.s[q.cnt++] = (it == old_to_new.end()) ? 0 : it->second;
+            }
+        }
+        out.push_back(q);
+    }
+    auto key = [k](const SepRec &q) { return (size_t)q.ix * k + (size_t)q.iy; };
+    if (!std::is_sorted(out.begin(), out.end(), [&](const SepRec &a, const SepRec &b) { return key(a) < key(b); }))
+        std::stable_sort(out.begin(), out.end(), [&](const SepRec &a, const SepRec &b) { return key(a) < key(b); });
+    for (size_t i = 1; i < out.size(); i++)
+        if (key(out[i]) == key(out[i - 1]))
+        {
+            out.clear();
+            return false;
+        }
+    return true;
 }
 
 inline std::vector<int> compose(const std::vector<int> &P, const std::vector<int> *index_map)
@@ -544,7 +653,9 @@ inline bool run_cusk_block(cusk_engine *e, const CuskInputs &in, int block_index
     out.new_to_old = compose(P2, &gcs.new_to_old);
     out.G = gather_adj(G2, P2);
     out.C = gather(e, scr.C2.p, k, P2);
-    out.S = reduce_sepsets(e, P2, ML, &gcs.new_to_old);
+    // (the sets as a list; the 18 MB dense array only for callers that ask for it, the .sep file is streamed)
+    out.sep_sparse = reduce_sepsets_sparse(e, P2, ML, &gcs.new_to_old, out.sep_recs);
+    if (!out.sep_sparse) out.S = reduce_sepsets(e, P2, ML, &gcs.new_to_old);
     bs.retained = (long long)out.num_markers();
     if (log) *log << "Retained " << out.num_markers() << " markers" << std::endl;
     bs.ms_reduce = ms_since(t);
