@@ -302,23 +302,16 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
     // reduce_sepsets does, including the stage-two remap quirk: a member s (an index of the stage-two
     // space) is looked up in a map keyed by the STAGE-ONE index of the retained variables
     {
-        // the dense k x k x 14 arrays of the blocks (megabytes of -1, fresh pages) are filled by helper threads while this
-        // one waits for the records to arrive from the device
-        std::vector<std::thread> fillers;
+        // (round 3, second form: the sets stay a sorted list per block -- Reduced::sep_recs -- and the dense k x k x 14 arrays
+        // are only built for a caller that asks for them; files and the packed form with_sep = 2 are made from the list)
+        for (int k = 0; k < K; k++)
         {
-            const int nth = std::min(3, K);
-            for (int t = 0; t < nth; t++)
-                fillers.emplace_back([&, t, nth]() {
-                    for (int k = t; k < K; k += nth)
-                    {
-                        Reduced &out = outs[(size_t)kept[(size_t)k]].r;
-                        out.S.assign(out.num_var * out.num_var * (size_t)ML, -1);
-                    }
-                });
+            Reduced &out = outs[(size_t)kept[(size_t)k]].r;
+            out.sep_sparse = true;
+            out.sep_recs.clear();
         }
         const int *x = nullptr, *y = nullptr, *rs = nullptr;  // engine-owned pinned memory
         const long long cnt = cusk_result_sepsets_view(e, &x, &y, &rs);
-        for (auto &th : fillers) th.join();
         if (cnt < 0) engine_die("sepsets (batch)", e);
         if (cnt > 0)
         {
@@ -347,17 +340,21 @@ inline void run_cusk_batch(cusk_engine *e, const CuskInputs &in, const StagedInp
                 const int ix = pos[(size_t)lx], iy = pos[(size_t)ly];
                 if (ix < 0 || iy < 0) continue;
                 Reduced &out = outs[(size_t)kept[(size_t)k]].r;
-                int *dst = &out.S[((size_t)ix * out.num_var + (size_t)iy) * (size_t)ML];
-                size_t c = 0;
+                SepRec q;
+                q.ix = ix;
+                q.iy = iy;
+                q.cnt = 0;
                 for (int l = 0; l < ML; l++)
                 {
                     const int sv = rs[(size_t)r * ML + (size_t)l];
                     if (sv == -1) continue;
                     const int ls = sv - lo2[(size_t)k];
-                    if (pos[(size_t)ls] >= 0) dst[c++] = (o2n[(size_t)ls] >= 0) ? o2n[(size_t)ls] : 0;
+                    if (pos[(size_t)ls] >= 0) q.s[q.cnt++] = (o2n[(size_t)ls] >= 0) ? o2n[(size_t)ls] : 0;
                 }
+                out.sep_recs.push_back(q);
             }
         }
+        for (int k = 0; k < K; k++) sort_sep_recs(outs[(size_t)kept[(size_t)k]].r);
     }
     mark("sepsets");
     bs.ms_reduce = ms_since(t);

@@ -334,17 +334,22 @@ extern "C" int cusk_batch_result_write(const cusk_batch_result *r, const char *o
     return CUSK_OK;
 }
 
-static size_t packed_bytes_of(const cusk_block_result &b, bool with_sep)
+// with_sep: 0 none, 1 the dense num_var^2 x max_level array, 2 the list (count, then SepRec after SepRec) -- results that
+// hold no list go out dense whatever was asked for (the head says which)
+static int sep_form_of(const cusk_block_result &b, int with_sep) { return (with_sep == 2 && !b.r.sep_sparse) ? 1 : with_sep; }
+static size_t packed_bytes_of(const cusk_block_result &b, int with_sep)
 {
     const size_t k = b.r.num_var;
-    return 24 + b.stem.size() + 4 * (k + 2 * k * k + (with_sep ? k * k * b.r.max_level : 0));
+    const int form = sep_form_of(b, with_sep);
+    const size_t sep = form == 1 ? 4 * k * k * b.r.max_level : (form == 2 ? 4 + sizeof(SepRec) * b.r.sep_recs.size() : 0);
+    return 24 + b.stem.size() + 4 * (k + 2 * k * k) + sep;
 }
 
 extern "C" size_t cusk_batch_result_packed_bytes_ex(const cusk_batch_result *r, int with_sep)
 {
     size_t t = 0;
     if (r)
-        for (const cusk_block_result &b : r->blocks) t += packed_bytes_of(b, with_sep != 0);
+        for (const cusk_block_result &b : r->blocks) t += packed_bytes_of(b, with_sep);
     return t;
 }
 extern "C" size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r) { return cusk_batch_result_packed_bytes_ex(r, 1); }
@@ -360,7 +365,8 @@ extern "C" int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, 
     for (size_t i = 0; i < r->blocks.size(); i++)
     {
         const cusk_block_result &b = r->blocks[i];
-        const int head[6] = {r->index[i], (int)b.r.num_var, (int)b.r.num_phen, (int)b.r.max_level, with_sep ? 1 : 0, (int)b.stem.size()};
+        const int form = sep_form_of(b, with_sep);
+        const int head[6] = {r->index[i], (int)b.r.num_var, (int)b.r.num_phen, (int)b.r.max_level, form, (int)b.stem.size()};
         std::memcpy(p, head, 24);
         p += 24;
         std::memcpy(p, b.stem.data(), b.stem.size());
@@ -372,7 +378,14 @@ extern "C" int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, 
         put(b.r.new_to_old.data(), 4 * b.r.new_to_old.size());
         put(b.r.G.data(), 4 * b.r.G.size());
         put(b.r.C.data(), 4 * b.r.C.size());
-        if (with_sep) put(b.r.dense_sep().data(), 4 * b.r.dense_sep().size());
+        if (form == 1)
+            put(b.r.dense_sep().data(), 4 * b.r.dense_sep().size());
+        else if (form == 2)
+        {
+            const int nrec = (int)b.r.sep_recs.size();
+            put(&nrec, 4);
+            put(b.r.sep_recs.data(), sizeof(SepRec) * b.r.sep_recs.size());
+        }
     }
     return CUSK_OK;
 }
@@ -401,8 +414,10 @@ extern "C" int cusk_merge_packed(const char *blockfile, const void *buf, size_t 
             std::memcpy(head, p, 24);
             p += 24;
             const size_t k = (size_t)head[1], ml = (size_t)head[3], ns = (size_t)head[5];
-            const bool has_sep = head[4] != 0;
-            if ((size_t)(end - p) < ns + 4 * (k + 2 * k * k + (has_sep ? k * k * ml : 0))) throw std::runtime_error("truncated packed results");
+            const int form = head[4];  // separating sets: 0 none, 1 dense, 2 list (skipped here either way)
+            if (form < 0 || form > 2) throw std::runtime_error("packed results: unknown separating-set form");
+            if ((size_t)(end - p) < ns + 4 * (k + 2 * k * k + (form == 1 ? k * k * ml : 0)) + (form == 2 ? 4 : 0))
+                throw std::runtime_error("truncated packed results");
             const std::string stem(p, ns);
             p += ns;
             auto it = where.find(stem);
@@ -417,7 +432,16 @@ extern "C" int cusk_merge_packed(const char *blockfile, const void *buf, size_t 
             p += 4 * k * k;
             std::memcpy(corr[at].data(), p, 4 * k * k);
             p += 4 * k * k;
-            if (has_sep) p += 4 * k * k * ml;
+            if (form == 1)
+                p += 4 * k * k * ml;
+            else if (form == 2)
+            {
+                int nrec = 0;
+                std::memcpy(&nrec, p, 4);
+                p += 4;
+                if (nrec < 0 || (size_t)(end - p) < sizeof(SepRec) * (size_t)nrec) throw std::runtime_error("truncated packed results");
+                p += sizeof(SepRec) * (size_t)nrec;
+            }
             in[at].present = true;
             in[at].num_var = k;
             in[at].num_phen = (size_t)head[2];
@@ -458,8 +482,10 @@ extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const ch
             std::memcpy(head, p, 24);
             p += 24;
             const size_t k = (size_t)head[1], ml = (size_t)head[3], ns = (size_t)head[5];
-            const bool has_sep = head[4] != 0;
-            const size_t need = ns + 4 * (k + 2 * k * k + (has_sep ? k * k * ml : 0));
+            const int form = head[4];
+            const bool has_sep = form != 0;
+            if (form < 0 || form > 2) throw std::runtime_error("packed results: unknown separating-set form");
+            const size_t need = ns + 4 * (k + 2 * k * k + (form == 1 ? k * k * ml : 0)) + (form == 2 ? 4 : 0);
             if ((size_t)(end - p) < need) throw std::runtime_error("truncated packed results");
             parsed.emplace_back(new cusk_block_result());
             Reduced &r = parsed.back()->r;
@@ -476,7 +502,23 @@ extern "C" int cusk_packed_results_write(const void *buf, size_t bytes, const ch
             take(r.new_to_old, k);
             take(r.G, k * k);
             take(r.C, k * k);
-            if (has_sep) take(r.S, k * k * ml);
+            if (form == 1)
+                take(r.S, k * k * ml);
+            else if (form == 2)
+            {
+                int nrec = 0;
+                std::memcpy(&nrec, p, 4);
+                p += 4;
+                if (nrec < 0 || (size_t)(end - p) < sizeof(SepRec) * (size_t)nrec) throw std::runtime_error("truncated packed results");
+                r.sep_recs.resize((size_t)nrec);
+                std::memcpy(r.sep_recs.data(), p, sizeof(SepRec) * (size_t)nrec);
+                p += sizeof(SepRec) * (size_t)nrec;
+                for (const SepRec &q : r.sep_recs)
+                    if (q.ix < 0 || q.iy < 0 || (size_t)q.ix >= k || (size_t)q.iy >= k || q.cnt < 0 || (size_t)q.cnt > ml || q.cnt > ML)
+                        throw std::runtime_error("packed results: separating set outside the block");
+                r.sep_sparse = true;
+                sort_sep_recs(r);
+            }
             all_sep = all_sep && has_sep;
             if (blocks_written) (*blocks_written)++;
         }

@@ -171,6 +171,15 @@ struct Reduced
     }
 };
 
+// arrival order -> ascending cells; records of one cell keep their order (the later one overwrites the head of the earlier,
+// as in the dense reduction)
+inline void sort_sep_recs(Reduced &r)
+{
+    const size_t k = r.num_var;
+    auto less = [k](const SepRec &a, const SepRec &b) { return (size_t)a.ix * k + (size_t)a.iy < (size_t)b.ix * k + (size_t)b.iy; };
+    if (!std::is_sorted(r.sep_recs.begin(), r.sep_recs.end(), less)) std::stable_sort(r.sep_recs.begin(), r.sep_recs.end(), less);
+}
+
 // The .sep file of a sparse result: the array goes out in pieces of ~1 MB that are a whole number of cells, from ONE buffer
 // of -1 that is patched with the sets of the piece and restored afterwards -- no 18 MB array to fill and to read back
 // from memory (the buffer stays in cache), same bytes.

@@ -162,12 +162,13 @@ class BatchResult:
         if lib().cusk_batch_result_write(self.h, outdir.encode()) != 0:
             raise RuntimeError(f"writing batch results: {lib().cusk_blockset_last_error().decode()}")
 
-    def pack(self, with_sep: bool = True) -> np.ndarray:
+    def pack(self, with_sep=True) -> np.ndarray:
         """the results as one byte string (shard.BlockResult.pack layout, block after block); with_sep = False leaves the
         .sep arrays out (nine tenths of the bytes; the merge does not read them)"""
-        nbytes = int(lib().cusk_batch_result_packed_bytes_ex(self.h, 1 if with_sep else 0))
+        form = 2 if with_sep == 2 else (1 if with_sep else 0)  # 2: the separating sets as a list (C readers only)
+        nbytes = int(lib().cusk_batch_result_packed_bytes_ex(self.h, form))
         buf = np.zeros(nbytes, np.uint8)
-        if nbytes and lib().cusk_batch_result_pack_ex(self.h, buf.ctypes.data_as(C.c_void_p), nbytes, 1 if with_sep else 0) != 0:
+        if nbytes and lib().cusk_batch_result_pack_ex(self.h, buf.ctypes.data_as(C.c_void_p), nbytes, form) != 0:
             raise RuntimeError("cusk_batch_result_pack failed")
         return buf
 
@@ -511,7 +512,9 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
             if distributed:
                 dist.barrier(group)  # every rank's own files are on disk when the job returns
         else:
-            payload = np.concatenate([r.pack() for r in bres]) if bres else np.zeros(0, np.uint8)
+            # (with_sep = 2: the separating sets travel as a list -- a twentieth of the dense arrays; cusk_packed_results_write
+            # on rank 0 streams the .sep files from it)
+            payload = np.concatenate([r.pack(with_sep=2) for r in bres]) if bres else np.zeros(0, np.uint8)
             if distributed:
                 parts = gather_packed(payload, device=collective_device, group=group)
             else:
@@ -525,9 +528,13 @@ def run_job(bs, outdir: str | None, device: int, inflight: int = 1, schedule: st
                     pos = 0
                     while pos < part.size:  # block indices of what arrived (headers only)
                         head = part[pos:pos + 24].view(np.int32)
-                        bi, k, _nph, ml, has_sep, ns = (int(v) for v in head)
+                        bi, k, _nph, ml, form, ns = (int(v) for v in head)
                         done.append(bi)
-                        pos += 24 + ns + 4 * (k + 2 * k * k + (k * k * ml if has_sep else 0))
+                        pos += 24 + ns + 4 * (k + 2 * k * k)
+                        if form == 1:  # dense separating sets
+                            pos += 4 * k * k * ml
+                        elif form == 2:  # a list: int32 count + count records of 17 int32 (include/cusk_hip.h)
+                            pos += 4 + 68 * int(part[pos:pos + 4].view(np.int32)[0])
                     if outdir is not None and part.size:
                         write_packed(part, outdir)
                 done.sort()

@@ -383,7 +383,10 @@ int cusk_batch_result_write(const cusk_batch_result *r, const char *outdir);   /
 size_t cusk_batch_result_packed_bytes(const cusk_batch_result *r);
 int cusk_batch_result_pack(const cusk_batch_result *r, void *buf, size_t bytes);
 int cusk_packed_results_write(const void *buf, size_t bytes, const char *outdir, int *blocks_written);
-/* the same byte string without the .sep arrays (nine tenths of the bytes; with_sep = 0): what the merge below needs */
+/* the same byte string without the .sep arrays (nine tenths of the bytes; with_sep = 0): what the merge below needs.
+ * with_sep = 2: the separating sets as a list instead of the dense num_var^2 x max_level array -- head word 4 = 2, then an int32
+ * count and count records {int32 row, column, length, int32 members[14]} in ascending (row, column) order; understood by
+ * cusk_packed_results_write and cusk_merge_packed (not by the reference-side Python unpacker: use it between library calls). */
 size_t cusk_batch_result_packed_bytes_ex(const cusk_batch_result *r, int with_sep);
 int cusk_batch_result_pack_ex(const cusk_batch_result *r, void *buf, size_t bytes, int with_sep);
 /* `merge-block-outputs` (cusk_postprocessing/merge_blocks.py:361-395 + write_mm :298-325) on the packed results of a whole

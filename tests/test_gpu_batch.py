@@ -199,6 +199,19 @@ def test_batch_result_accessors_and_oracle(chromosome, oracle, tmp_path):
     assert rb.write_packed(br.pack(), str(out)) == 2
     for f in os.listdir(out):
         assert open(out / f, "rb").read() == open(os.path.join(str(chromosome["ref"]), f), "rb").read()
+    # the list form of the separating sets (what the rank-0 writer receives): a fraction of the bytes, the same files;
+    # and the merge reads past either form
+    out2 = tmp_path / "o2"
+    out2.mkdir()
+    sparse = br.pack(with_sep=2)
+    assert sparse.size < br.pack().size // 4 and rb.write_packed(sparse, str(out2)) == 2
+    assert sorted(os.listdir(out2)) == sorted(os.listdir(out))
+    for f in os.listdir(out2):
+        assert open(out2 / f, "rb").read() == open(out / f, "rb").read(), f
+    for k, form in enumerate((sparse, br.pack(), br.pack(with_sep=False))):
+        rb.merge_packed(chromosome["blocks"], form, str(tmp_path / f"m{k}"))
+    for suffix in ("_sam.mtx", "_scm.mtx", ".mdim", ".ixs"):
+        assert open(str(tmp_path / "m0") + suffix, "rb").read() == open(str(tmp_path / "m2") + suffix, "rb").read() == open(str(tmp_path / "m1") + suffix, "rb").read()
     br.free()
     lib_release = rb.lib().cusk_blockset_release_engine
     lib_release(bs.h, e.h)
