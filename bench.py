@@ -176,16 +176,21 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     from cigwas_amd import run_blocks as rb
 
     N, p = args.individuals, args.traits
+    # The synthetic INPUT files (350 MB per GPU's share: they are read once and staged in HBM) go to memory-backed storage
+    # when the box has it: written to disk they leave the file system throttling writers for seconds -- the result files
+    # of a SECOND bench run on the same box (the N = 1, 2, 4, 8 series) took 11-21 ms per pass instead of 1.9.  The
+    # RESULT files of the timed passes go where a job's files go: TMPDIR / /tmp.
     if rank == 0:
         workdir = tempfile.mkdtemp(prefix="cusk_bench_", dir=os.environ.get("TMPDIR", "/tmp"))
+        indir = tempfile.mkdtemp(prefix="cusk_bench_in_", dir=input_dir_root())
     else:
-        workdir = None
+        workdir = indir = None
     if dist is not None:
-        box = [workdir]
+        box = [workdir, indir]
         dist.broadcast_object_list(box, src=0)
-        workdir = box[0]
+        workdir, indir = box
     t0 = time.time()
-    phen, stem, blocks, sizes = write_chromosome(workdir, rank, world, args.blocks_per_gpu, N, p, dist)
+    phen, stem, blocks, sizes = write_chromosome(indir, rank, world, args.blocks_per_gpu, N, p, dist)
     t_gen = time.time() - t0
     # the synthetic inputs were written a moment ago (hundreds of MB of dirty pages): without this the kernel's write-back
     # throttling lands on the result files of the timed passes (measured: 15-20 ms instead of 2 ms per 25 blocks)
@@ -228,6 +233,8 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
     def timed(writer, K, W):
         for _ in range(W):
             one_pass(writer)
+        if rank == 0:
+            os.sync()  # the warm-up passes' files (and whatever the box wrote before) are on their way out before the clock starts
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -305,14 +312,31 @@ def chromosome_run(args, rank, world, device, cdev, dist, steps, warmup):
                    "one gather over "
                    + ("RCCL (backend nccl)" if cdev is not None else ("gloo" if dist is not None else "nothing (one rank)"))
                    + "; gather_ms / write_ms: rank 0's wall clock per pass for the exchange / for what it writes after it"),
-        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage); result files written inside the timed region",
+        "inputs": ".bed / .phen / means / stds staged in HBM once per GPU (cusk_blockset_stage; the synthetic input files live under "
+                  + input_dir_root() + "); result files written inside the timed region under " + os.environ.get("TMPDIR", "/tmp"),
         "curve_key": "scale.blocks_per_sec (same workload definition at every N: 25 blocks per GPU, weak scaling)",
         "generate_s": t_gen,
     }
     bs.close()
     if rank == 0:
         shutil.rmtree(workdir, ignore_errors=True)
+        shutil.rmtree(indir, ignore_errors=True)
     return scale, (lv_ms, lv_tests, lv_sub, nvar), dt, ca
+
+
+def input_dir_root():
+    """where the synthetic input files of a run are written: CUSK_BENCH_INPUT_DIR, else /dev/shm when it is a writable
+    directory with room, else TMPDIR / /tmp"""
+    d = os.environ.get("CUSK_BENCH_INPUT_DIR")
+    if d:
+        return d
+    try:
+        st = os.statvfs("/dev/shm")
+        if os.access("/dev/shm", os.W_OK) and st.f_bavail * st.f_frsize > (8 << 30):
+            return "/dev/shm"
+    except OSError:
+        pass
+    return os.environ.get("TMPDIR", "/tmp")
 
 
 def e2e_block(args, bed, phen, means, stds, device):
@@ -324,7 +348,8 @@ def e2e_block(args, bed, phen, means, stds, device):
     from cigwas_amd.skeleton import Engine
 
     m, p, N = args.markers, args.traits, args.individuals
-    d = tempfile.mkdtemp(prefix="cusk_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
+    d = tempfile.mkdtemp(prefix="cusk_e2e_in_", dir=input_dir_root())
+    dout = tempfile.mkdtemp(prefix="cusk_e2e_", dir=os.environ.get("TMPDIR", "/tmp"))
     try:
         stem = os.path.join(d, "blk")
         synth.write_bfiles(stem, bed, N, means, stds)
@@ -334,7 +359,7 @@ def e2e_block(args, bed, phen, means, stds, device):
         eng = Engine(device)
         eng.set_option("timing", 0)
         bs.stage(eng)
-        out = os.path.join(d, "out")
+        out = os.path.join(dout, "out")
         os.makedirs(out)
         walls, phases = [], {}
         os.sync()  # (the input files were written a moment ago: keep their write-back out of the result files' way)
@@ -361,6 +386,7 @@ def e2e_block(args, bed, phen, means, stds, device):
         return res
     finally:
         shutil.rmtree(d, ignore_errors=True)
+        shutil.rmtree(dout, ignore_errors=True)
 
 
 def main():

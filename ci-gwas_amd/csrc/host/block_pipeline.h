@@ -215,8 +215,9 @@ inline void write_sep_streaming(const std::string &path, const Reduced &r)
 inline void write_reduced(const Reduced &r, const std::string &base, bool with_sep)
 {
     {
-        std::ofstream f(base + ".mdim");
-        f << r.num_var << "\t" << r.num_phen << "\t" << r.max_level << std::endl;
+        char line[96];
+        const int len = std::snprintf(line, sizeof(line), "%zu\t%zu\t%zu\n", r.num_var, r.num_phen, r.max_level);
+        write_binary(base + ".mdim", line, (size_t)len);
     }
     write_binary(base + ".ixs", r.new_to_old.data(), r.new_to_old.size());
     write_binary(base + ".adj", r.G.data(), r.G.size());
