@@ -491,6 +491,11 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                 // the run's one mandatory round trip: sizes of the CSR arrays and of the binomial table come from the
                 // level-1 degrees
                 hp_mark("plan1_enq");
+                // (the record store of a previous run is cleared while the gate record travels: the clear needs no number
+                // from the device unless the store has to grow)
+                int *const rec_l_before = (a.mode == 0) ? e->rec_l.as<int>() : nullptr;
+                const size_t rec_l_cleared = rec_l_before ? e->rec_l.cap : 0;
+                if (rec_l_cleared) CUSK_HIP(e, hipMemsetAsync(rec_l_before, 0, rec_l_cleared, s));
                 int rc = wait_gate(1);
                 if (rc != CUSK_OK) return rc;
                 hp_mark("gate1");
@@ -514,7 +519,8 @@ static int run_levels(cusk_engine *e, const RunArgs &a, cusk_stats *st)
                     e->rec_cap = (long long)(e->rec_l.cap / sizeof(int));
                     if ((long long)(e->rec_s.cap / (sizeof(int) * kML)) < e->rec_cap) e->rec_cap = (long long)(e->rec_s.cap / (sizeof(int) * kML));
                     e->rec_slots = cap_edges;
-                    CUSK_HIP(e, hipMemsetAsync(e->rec_l.p, 0, sizeof(int) * (size_t)cap_edges, s));  // no records yet
+                    if (e->rec_l.as<int>() != rec_l_before || rec_l_cleared < sizeof(int) * (size_t)cap_edges)
+                        CUSK_HIP(e, hipMemsetAsync(e->rec_l.p, 0, sizeof(int) * (size_t)cap_edges, s));  // no records yet
                     CUSK_HIP(e, e->wpre.ensure(sizeof(int) * (size_t)n * words));
                 }
                 CUSK_HIP(e, e->queue.ensure(sizeof(RecheckEntry) * (size_t)e->opt_queue_cap));
